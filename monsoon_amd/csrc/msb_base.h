@@ -1,0 +1,90 @@
+// Monsoon-AMD: shared base definitions for the batched Stormbound rules core.
+//
+// The rules core (rules.h, features.h) is ONE source compiled twice:
+//   * by hipcc for gfx950 inside the product kernels (monsoon_hip.hip), where
+//     every state access goes through a lane-interleaved LDS accessor, and
+//   * by g++ for the host inside oracle/ (test infrastructure only), where the
+//     same accessor interface is backed by a plain byte array.
+// Nothing in the product library calls the host build.
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define MSB_HD __device__
+#define MSB_NOINLINE __attribute__((noinline))
+#else
+#define MSB_HD
+#define MSB_NOINLINE __attribute__((noinline))
+#endif
+#define MSB_INL inline __attribute__((always_inline))
+
+namespace msb {
+
+// ---- enums (reference enums.py) -------------------------------------------------------
+enum : int { KIND_UNIT = 0, KIND_STRUCT = 1, KIND_SPELL = 2 };
+// TriggerType, enums.py:69-79
+enum : int { TR_NONE = -1, TR_ON_PLAY = 0, TR_ON_DEATH = 1, TR_BEFORE_ATTACKING = 2, TR_AFTER_ATTACKING = 3,
+             TR_AFTER_SURVIVING = 4, TR_BEFORE_MOVING = 5, TR_TURN_START = 6, TR_TURN_END = 7 };
+// StatusEffect, enums.py:81-86
+enum : int { ST_FROZEN = 0, ST_POISONED = 1, ST_CONFUSED = 2, ST_DISABLED = 3, ST_VITALIZED = 4 };
+// Phase, enums.py:88-91
+enum : int { PH_TURN_START = 0, PH_PLAY = 1, PH_TURN_END = 2 };
+// UnitType, enums.py:51-67
+enum : int { UT_CONSTRUCT = 0, UT_FLAKE, UT_KNIGHT, UT_PIRATE, UT_RAVEN, UT_RODENT, UT_SATYR, UT_TOAD, UT_UNDEAD,
+             UT_VIKING, UT_HERO, UT_DRAGON, UT_ELDER, UT_FELINE, UT_ANCIENT, UT_PRIMAL };
+// Target.Kind / Target.Side, target.py:8-16
+enum : int { TK_UNIT = 0, TK_STRUCTURE = 1, TK_ANY = 2 };
+enum : int { TS_FRIENDLY = 0, TS_ENEMY = 1, TS_ANY = 2 };
+
+// Per-game fault codes: the reference raises Python exceptions that its agent layer swallows
+// (evo/heuristic_agent.py:48-51, evo/fitness.py:208-210); here a step that would raise sets a
+// fault byte instead.  Codes >= FAULT_CAPACITY are build limits, not reference behaviour; the
+// tests require them to be zero on every benchmark configuration.
+enum : int {
+  FAULT_NONE = 0,
+  FAULT_PY_EXCEPTION = 1,   // reference raises (u310/u017/s101, Point.__eq__(None), ...)
+  FAULT_INT_CARD = 2,       // int(card) ValueError for up01/up02/up03 (card.py:46)
+  FAULT_CAPACITY = 16,      // entity slots / deck / path capacity
+  FAULT_TRIG_STACK = 17,    // deferred-trigger stack overflow
+  FAULT_DEPTH = 18,         // recursion guard
+  FAULT_RNG_OVERRUN = 19,   // one step consumed more than the two resident MT blocks
+  FAULT_UNSUPPORTED = 20,   // card ability not implemented yet in this build
+  FAULT_STATUS_SAT = 21,    // status multiset count saturated
+};
+
+// ---- static card table -----------------------------------------------------------------
+struct TargetSpec {
+  int8_t has, kind, side;
+  uint16_t types, xtypes;
+  int16_t limit;  // -1 = None
+  int8_t non_hero;
+  uint8_t status, xstatus;
+  int8_t base;
+};
+struct CardInfo {
+  int8_t kind, faction;
+  uint8_t cost, strength, movement;
+  int8_t trigger, ff, has_ability;
+  uint16_t types;
+  int8_t first_type;
+  int32_t int_id;
+  TargetSpec tgt;
+};
+
+constexpr int NUM_CARDS = 112;
+constexpr int TOKEN_UNIT_BASE = 112;   // + UnitType
+constexpr int TOKEN_STRUCT = 128;
+constexpr int CARD_NONE = 0xFF;
+
+#if defined(__HIPCC__)
+__device__ __constant__
+#endif
+static const CardInfo g_cards[NUM_CARDS] = {
+#include "card_table.inc"
+};
+
+// Card indices used by name in rules.h (sorted-id order; checked against card_ids.json by tests).
+#include "card_names.inc"
+
+}  // namespace msb

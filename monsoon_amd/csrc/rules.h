@@ -1,0 +1,1220 @@
+// Stormbound rules core: one game step, restated from the reference's object engine for a
+// flat state record (state.h).  Compiled for gfx950 (product) and for the host (oracle).
+//
+// Every function cites the reference code it restates.  The reference's bugs are reproduced on
+// purpose: targeted spells land one tile late, Player.opponent is
+// `self` on every second turn, statuses are multisets, dead units keep walking a cached path,
+// turn-start movement iterates a snapshot of entity objects, and deferred triggers are a LIFO
+// stack with a non-counting re-entrancy latch.
+//
+// Control flow: the reference recurses (move -> ability -> deal_damage -> destroy -> ability ->
+// command -> move ...).  The recursion is kept (hipcc supports it on gfx950 with a dynamic
+// scratch stack); only the tail call at the end of the ability wrapper (card.py:54-60) is a loop.
+#pragma once
+#include "mt19937.h"
+#include "state.h"
+
+namespace msb {
+
+struct P {
+  int x, y;
+};
+MSB_HD MSB_INL bool p_valid(P p) { return p.x >= 0 && p.x <= 3 && p.y >= 0 && p.y <= 4; }        // point.py:15-17
+MSB_HD MSB_INL bool p_is_base(P p) { return p.x == -1 && (p.y == -1 || p.y == 5); }              // point.py:19-21
+MSB_HD MSB_INL bool p_eq(P a, P b) { return a.x == b.x && a.y == b.y; }
+MSB_HD MSB_INL int p_pack(P p) { return ((p.y + 1) << 3) | (p.x + 1); }                          // x in [-1,6], y in [-1,5]
+MSB_HD MSB_INL P p_unpack(int v) { return P{(v & 7) - 1, (v >> 3) - 1}; }
+MSB_HD MSB_INL int p_tile(P p) { return p.y * 4 + p.x; }
+MSB_HD MSB_INL P tile_p(int t) { return P{t & 3, t >> 2}; }
+constexpr int PK_NONE = 0xFF;
+
+struct PList {
+  int n;
+  uint8_t v[24];
+  MSB_HD MSB_INL void clear() { n = 0; }
+  MSB_HD MSB_INL void push(P p) {
+    if (n < 24) v[n++] = (uint8_t)p_pack(p);
+  }
+  MSB_HD MSB_INL P at(int i) const { return p_unpack(v[i]); }
+  MSB_HD MSB_INL bool has(P p) const {
+    int k = p_pack(p);
+    for (int i = 0; i < n; i++)
+      if (v[i] == k) return true;
+    return false;
+  }
+  MSB_HD MSB_INL void remove_at(int i) {
+    for (int j = i; j + 1 < n; j++) v[j] = v[j + 1];
+    n--;
+  }
+};
+
+// Target descriptor (target.py:18-29)
+struct Tgt {
+  int kind, side;
+  int types, xtypes;   // UnitType masks, 0 = None
+  int limit;           // strength_limit, LIMIT_NONE = None
+  int non_hero;
+  int status, xstatus; // StatusEffect masks, 0 = None
+  int base;            // include_base
+};
+constexpr int LIMIT_NONE = -32768;
+MSB_HD MSB_INL Tgt mk_tgt(int kind, int side) { return Tgt{kind, side, 0, 0, LIMIT_NONE, 0, 0, 0, 0}; }
+MSB_HD MSB_INL Tgt mk_tgt(const TargetSpec& s) {
+  return Tgt{s.kind, s.side, s.types, s.xtypes, s.limit < 0 ? LIMIT_NONE : s.limit, s.non_hero, s.status, s.xstatus, s.base};
+}
+
+// Results of Board.at (board.py:58-65)
+constexpr int AT_NONE = -1;
+constexpr int AT_PLAYER = 64;   // + PlayerOrder
+
+enum : int { SH_FRONT, SH_BEHIND, SH_SIDE, SH_ROW, SH_COLUMN, SH_BORDERING, SH_SURROUNDING };
+
+constexpr int MAX_DEPTH = 40;
+
+template <class M>
+struct Engine {
+  M m;
+  RngView rng;
+
+  // ------------------------------------------------------------------------------------------
+  // raw field access
+  // ------------------------------------------------------------------------------------------
+  MSB_HD MSB_INL int fault() const { return m.ld8(H_FAULT); }
+  MSB_HD MSB_INL void set_fault(int code) {
+    if (m.ld8(H_FAULT) == 0) m.st8(H_FAULT, code);
+  }
+  MSB_HD MSB_INL int local() const { return m.ld8(H_TOPLAY); }     // order of board.local
+  MSB_HD MSB_INL int remote() const { return m.ld8(H_TOPLAY) ^ 1; }
+  MSB_HD MSB_INL int cp() const { return m.ld8(H_CP); }            // order of board.current_player
+  MSB_HD MSB_INL int phase() const { return m.ld8(H_PHASE); }
+
+  MSB_HD MSB_INL int pl(int order, int f) const { return OFF_PL + order * PL_SIZE + f; }
+  MSB_HD MSB_INL int pl_base(int o) const { return m.ld16(pl(o, P_BASE)); }
+  MSB_HD MSB_INL void set_pl_base(int o, int v) { m.st16(pl(o, P_BASE), v); }
+  MSB_HD MSB_INL int pl_mana(int o) const { return m.ld16(pl(o, P_MANA)); }
+  MSB_HD MSB_INL void set_pl_mana(int o, int v) { m.st16(pl(o, P_MANA), v); }
+  MSB_HD MSB_INL int pl_maxmana(int o) const { return m.ld16(pl(o, P_MAXMANA)); }
+  MSB_HD MSB_INL int pl_front(int o) const { return m.ld8(pl(o, P_FRONT)); }
+  MSB_HD MSB_INL void set_pl_front(int o, int v) { m.st8(pl(o, P_FRONT), v); }
+  MSB_HD MSB_INL int pl_hand_n(int o) const { return m.ld8(pl(o, P_HAND_N)); }
+  MSB_HD MSB_INL int pl_deck_n(int o) const { return m.ld8(pl(o, P_DECK_N)); }
+  MSB_HD MSB_INL int hand_card(int o, int i) const { return m.ld8(pl(o, P_HAND + 4 * i)); }
+  MSB_HD MSB_INL int hand_cost(int o, int i) const { return m.ld8(pl(o, P_HAND + 4 * i + 1)); }
+  MSB_HD MSB_INL int hand_flags(int o, int i) const { return m.ld8(pl(o, P_HAND + 4 * i + 2)); }
+  MSB_HD MSB_INL int deck_card(int o, int i) const { return m.ld8(pl(o, P_DECK + 4 * i)); }
+  MSB_HD MSB_INL int deck_cost(int o, int i) const { return m.ld8(pl(o, P_DECK + 4 * i + 1)); }
+  MSB_HD MSB_INL int deck_flags(int o, int i) const { return m.ld8(pl(o, P_DECK + 4 * i + 2)); }
+  MSB_HD MSB_INL double deck_w(int o, int i) const { return m.ldf(pl(o, P_WEIGHT + 8 * i)); }
+  MSB_HD MSB_INL void set_deck_w(int o, int i, double w) { m.stf(pl(o, P_WEIGHT + 8 * i), w); }
+
+  MSB_HD MSB_INL int board_at(int tile) const { return m.ld8(OFF_BOARD + tile); }
+  MSB_HD MSB_INL void board_put(int tile, int slot) { m.st8(OFF_BOARD + tile, slot); }
+
+  MSB_HD MSB_INL int e_card(int e) const { return m.ld8(E_CARD + e); }
+  MSB_HD MSB_INL int e_flags(int e) const { return m.ld8(E_FLAGS + e); }
+  MSB_HD MSB_INL int e_owner(int e) const { return m.ld8(E_FLAGS + e) & EF_OWNER; }
+  MSB_HD MSB_INL bool e_ff(int e) const { return (m.ld8(E_FLAGS + e) & EF_FF) != 0; }
+  MSB_HD MSB_INL void e_set_flag(int e, int bit, bool on) {
+    int f = m.ld8(E_FLAGS + e);
+    m.st8(E_FLAGS + e, on ? (f | bit) : (f & ~bit));
+  }
+  MSB_HD MSB_INL P e_pos(int e) const { return tile_p(m.ld8(E_POS + e)); }
+  MSB_HD MSB_INL void e_set_pos(int e, P p) { m.st8(E_POS + e, p_tile(p)); }
+  MSB_HD MSB_INL int e_mov(int e) const { return m.ld8(E_MOV + e); }
+  MSB_HD MSB_INL int e_str(int e) const { return m.ld16(E_STR + 2 * e); }
+  MSB_HD MSB_INL void e_set_str(int e, int v) { m.st16(E_STR + 2 * e, v); }
+  MSB_HD MSB_INL int e_dmg(int e) const { return m.ld16(E_DMG + 2 * e); }
+  MSB_HD MSB_INL void e_set_dmg(int e, int v) { m.st16(E_DMG + 2 * e, v); }
+  MSB_HD MSB_INL int e_st(int e, int s) const { return m.ld8(E_ST + s * NUM_ENT + e); }
+  MSB_HD MSB_INL void e_st_add(int e, int s) {
+    int c = m.ld8(E_ST + s * NUM_ENT + e);
+    if (c >= 255) {
+      set_fault(FAULT_STATUS_SAT);
+      return;
+    }
+    m.st8(E_ST + s * NUM_ENT + e, c + 1);
+  }
+  // list.remove(x) raises ValueError when x is absent
+  MSB_HD MSB_INL void e_st_remove(int e, int s) {
+    int c = m.ld8(E_ST + s * NUM_ENT + e);
+    if (c == 0) {
+      set_fault(FAULT_PY_EXCEPTION);
+      return;
+    }
+    m.st8(E_ST + s * NUM_ENT + e, c - 1);
+  }
+
+  // ---- card statics (tokens: board.py:298-322) -------------------------------------------------
+  MSB_HD MSB_INL bool card_is_unit(int c) const {
+    return c < NUM_CARDS ? g_cards[c].kind == KIND_UNIT : (c >= TOKEN_UNIT_BASE && c < TOKEN_UNIT_BASE + 16);
+  }
+  MSB_HD MSB_INL bool card_is_struct(int c) const { return c < NUM_CARDS ? g_cards[c].kind == KIND_STRUCT : c == TOKEN_STRUCT; }
+  MSB_HD MSB_INL int card_types(int c) const { return c < NUM_CARDS ? g_cards[c].types : (c < TOKEN_STRUCT ? (1 << (c - TOKEN_UNIT_BASE)) : 0); }
+  MSB_HD MSB_INL int card_first_type(int c) const { return c < NUM_CARDS ? g_cards[c].first_type : c - TOKEN_UNIT_BASE; }
+  MSB_HD MSB_INL int card_trigger(int c) const { return c < NUM_CARDS ? g_cards[c].trigger : TR_NONE; }
+  MSB_HD MSB_INL bool card_has_ability(int c) const { return c < NUM_CARDS ? g_cards[c].has_ability != 0 : false; }
+  // int(card), card.py:25-46.  Returns -1 where the reference raises ValueError.
+  MSB_HD MSB_INL int card_int_id(int c) const {
+    if (c < NUM_CARDS) return g_cards[c].int_id;
+    if (c == TOKEN_STRUCT) return 1;                               // card_id "b001"
+    int t = c - TOKEN_UNIT_BASE;                                   // "f" + str(t).zfill(3) parsed as hex
+    return 0x4000 + (t < 10 ? t : 0x10 + (t - 10));
+  }
+  MSB_HD MSB_INL bool e_is_unit(int e) const { return card_is_unit(e_card(e)); }
+  MSB_HD MSB_INL int e_trigger(int e) const {  // Unit.trigger; Structures have no .trigger attribute
+    int c = e_card(e);
+    return card_is_unit(c) ? card_trigger(c) : TR_NONE;
+  }
+  MSB_HD MSB_INL bool e_disabled(int e) const { return e_st(e, ST_DISABLED) > 0; }
+  MSB_HD MSB_INL bool e_confused(int e) const { return e_st(e, ST_CONFUSED) > 0; }
+  MSB_HD MSB_INL bool e_frozen(int e) const { return e_st(e, ST_FROZEN) > 0; }
+
+  // ------------------------------------------------------------------------------------------
+  // Board primitives
+  // ------------------------------------------------------------------------------------------
+  // Board.at, board.py:58-65
+  MSB_HD MSB_INL int at(P p) const {
+    if (p_is_base(p)) return AT_PLAYER + (p.y == 5 ? local() : remote());
+    if (!p_valid(p)) return AT_NONE;
+    int s = board_at(p_tile(p));
+    return s == SLOT_NONE ? AT_NONE : s;
+  }
+  // Board.set, board.py:67-71
+  MSB_HD MSB_INL void board_set(P p, int e) {
+    board_put(p_tile(p), e < 0 ? SLOT_NONE : e);
+    if (e >= 0) e_set_pos(e, p);
+  }
+
+  // A free entity slot: not on the board and not referenced since the step began.
+  MSB_HD MSB_NOINLINE int alloc_entity() {
+    uint32_t used = m.ld32(H_USED);
+    for (int e = 0; e < NUM_ENT; e++) {
+      if (!(used & (1u << e))) {
+        m.st32(H_USED, used | (1u << e));
+        return e;
+      }
+    }
+    set_fault(FAULT_CAPACITY);
+    return 0;
+  }
+  // Called at the start of every step: everything not on the board is garbage in the reference
+  // (no live Python reference survives a step).
+  MSB_HD MSB_NOINLINE void begin_step() {
+    uint32_t used = 0;
+    for (int t = 0; t < 20; t++) {
+      int s = board_at(t);
+      if (s != SLOT_NONE) used |= 1u << s;
+    }
+    m.st32(H_USED, used);
+    for (int e = 0; e < NUM_ENT; e++)
+      if (!(used & (1u << e))) m.st8(E_CARD + e, CARD_NONE);
+    m.st8(H_DEPTH, 0);
+  }
+  MSB_HD MSB_NOINLINE int new_entity(int card, int owner, int strength, int movement, bool ff) {
+    int e = alloc_entity();
+    if (fault()) return e;
+    m.st8(E_CARD + e, card);
+    m.st8(E_FLAGS + e, (owner ? EF_OWNER : 0) | (ff ? EF_FF : 0));
+    m.st8(E_POS + e, 0);
+    m.st8(E_MOV + e, movement);
+    for (int s = 0; s < 5; s++) m.st8(E_ST + s * NUM_ENT + e, 0);
+    m.st8(E_MOVEID + e, 0);
+    m.st8(E_PATHN + e, 0);
+    e_set_str(e, strength);
+    e_set_dmg(e, 0);
+    m.st32(E_PATH + 4 * e, 0);
+    return e;
+  }
+
+  // Board.calculate_front_line, board.py:78-92.  `player` is an order; the reference compares
+  // Player objects by order (player.py:39-40).
+  MSB_HD MSB_NOINLINE void calculate_front_line(int player) {
+    if (player == local()) {
+      int fl = 4;
+      for (int y = 0; y < 5; y++) {
+        bool any = false;
+        for (int x = 0; x < 4; x++) {
+          int s = board_at(y * 4 + x);
+          if (s != SLOT_NONE && e_owner(s) == player) any = true;
+        }
+        if (any) {
+          fl = y > 1 ? y : 1;
+          break;
+        }
+      }
+      set_pl_front(local(), fl);
+    } else {
+      int fl = 0;
+      for (int y = 4; y >= 0; y--) {
+        bool any = false;
+        for (int x = 0; x < 4; x++) {
+          int s = board_at(y * 4 + x);
+          if (s != SLOT_NONE && e_owner(s) == player) any = true;
+        }
+        if (any) {
+          fl = y < 3 ? y : 3;
+          break;
+        }
+      }
+      set_pl_front(remote(), fl);
+    }
+  }
+  // board.calculate_front_line(board.current_player.opponent), unit.py:231 / structure.py:69.
+  // Player.opponent (player.py:42-44) is board.remote for the FIRST player, board.local for the
+  // SECOND -- i.e. the second player's "opponent" is itself while it is the mover (fact #3).
+  MSB_HD MSB_INL int opponent_of(int order) const { return order == 0 ? remote() : local(); }
+  MSB_HD MSB_INL void recalc_front_after_destroy() { calculate_front_line(opponent_of(cp())); }
+
+  // Board.get_targets, board.py:147-204
+  MSB_HD MSB_NOINLINE void get_targets(PList& out, int pov, const Tgt& t, int exclude_pk) {
+    out.clear();
+    bool asc = (pov == local());
+    for (int i = 0; i < 20; i++) {
+      int tile = asc ? i : 19 - i;
+      int e = board_at(tile);
+      if (e == SLOT_NONE) continue;
+      int str = e_str(e);
+      if (str <= 0) continue;
+      int c = e_card(e);
+      bool is_unit = card_is_unit(c);
+      bool strength_ok = t.limit == LIMIT_NONE || str <= t.limit;
+      bool ok;
+      if (is_unit) {
+        int ty = card_types(c);
+        bool type_ok = t.types == 0 || (ty & t.types) != 0;
+        bool xtype_ok = t.xtypes == 0 || (ty & t.xtypes) == 0;
+        bool hero_ok = !t.non_hero || !(ty & (1 << UT_HERO));
+        int stm = 0;
+        if (t.status | t.xstatus)
+          for (int s = 0; s < 5; s++)
+            if (e_st(e, s) > 0) stm |= 1 << s;
+        bool st_ok = t.status == 0 || (stm & t.status) != 0;
+        bool xst_ok = t.xstatus == 0 || (stm & t.xstatus) == 0;
+        ok = type_ok && xtype_ok && hero_ok && st_ok && xst_ok && strength_ok && (t.kind == TK_ANY || t.kind == TK_UNIT);
+      } else {
+        ok = strength_ok && (t.kind == TK_ANY || t.kind == TK_STRUCTURE);
+      }
+      if (!ok) continue;
+      int own = e_owner(e);
+      bool side_ok = t.side == TS_ANY || (t.side == TS_FRIENDLY && own == pov) || (t.side == TS_ENEMY && own != pov);
+      if (side_ok) out.push(tile_p(tile));
+    }
+    if (t.base) {
+      P friendly = asc ? P{-1, 5} : P{-1, -1};
+      P enemy = asc ? P{-1, -1} : P{-1, 5};
+      if (t.side == TS_FRIENDLY || t.side == TS_ANY) out.push(friendly);
+      if (t.side == TS_ENEMY || t.side == TS_ANY) out.push(enemy);
+    }
+    if (exclude_pk != PK_NONE) {
+      for (int i = 0; i < out.n; i++)
+        if (out.v[i] == exclude_pk) {
+          out.remove_at(i);
+          break;
+        }
+    }
+  }
+
+  // membership of `p` in the raw tile list of a geometric selector (board.py:206-296)
+  MSB_HD MSB_INL bool in_shape(int shape, P c, int pov, P p) const {
+    int dx = p.x - c.x, dy = p.y - c.y;
+    switch (shape) {
+      case SH_FRONT: return dx == 0 && (pov == local() ? (p.y < c.y && p.y >= 0) : (p.y > c.y && p.y <= 4));
+      case SH_BEHIND: return dx == 0 && (pov == local() ? (p.y > c.y && p.y <= 4) : (p.y < c.y && p.y >= 0));
+      case SH_SIDE: return dy == 0 && (dx == 1 || dx == -1);
+      case SH_ROW: return dy == 0 && p.x >= 0 && p.x < 4;
+      case SH_COLUMN: return dx == 0 && p.y >= 0 && p.y < 5;
+      case SH_BORDERING: return (dy == 0 && (dx == 1 || dx == -1)) || (dx == 0 && (dy == 1 || dy == -1));
+      default: return !(dx == 0 && dy == 0) && dx >= -1 && dx <= 1 && dy >= -1 && dy <= 1;
+    }
+  }
+  // get_front_tiles .. get_surrounding_tiles WITHOUT a target: fixed enumeration order.
+  MSB_HD MSB_NOINLINE void shape_tiles(PList& out, int shape, P c, int pov) {
+    out.clear();
+    switch (shape) {
+      case SH_FRONT:
+        if (pov == local()) {
+          for (int y = c.y - 1; y >= 0; y--) out.push(P{c.x, y});
+        } else {
+          for (int y = c.y + 1; y < 5; y++) out.push(P{c.x, y});
+        }
+        break;  // the trailing sort (board.py:217) keeps this order
+      case SH_BEHIND:
+        if (pov == local()) {
+          for (int y = c.y + 1; y < 5; y++) out.push(P{c.x, y});
+        } else {
+          for (int y = c.y - 1; y >= 0; y--) out.push(P{c.x, y});
+        }
+        break;
+      case SH_SIDE: {
+        P a{c.x - 1, c.y}, b{c.x + 1, c.y};
+        if (p_valid(a)) out.push(a);
+        if (p_valid(b)) out.push(b);
+      } break;
+      case SH_ROW:
+        for (int x = 0; x < 4; x++) {
+          P a{x, c.y};
+          if (p_valid(a)) out.push(a);
+        }
+        break;
+      case SH_COLUMN:
+        for (int y = 0; y < 5; y++) {
+          P a{c.x, y};
+          if (p_valid(a)) out.push(a);
+        }
+        break;
+      case SH_BORDERING: {
+        const int dx[4] = {-1, 1, 0, 0}, dy[4] = {0, 0, -1, 1};
+        for (int i = 0; i < 4; i++) {
+          P a{c.x + dx[i], c.y + dy[i]};
+          if (p_valid(a)) out.push(a);
+        }
+      } break;
+      default: {
+        const int dx[8] = {-1, -1, -1, 1, 1, 1, 0, 0}, dy[8] = {0, -1, 1, 0, -1, 1, -1, 1};
+        for (int i = 0; i < 8; i++) {
+          P a{c.x + dx[i], c.y + dy[i]};
+          if (p_valid(a)) out.push(a);
+        }
+      } break;
+    }
+  }
+  // ... WITH a target: get_targets order filtered by membership; front/behind re-sorted by y.
+  MSB_HD MSB_NOINLINE void shape_targets(PList& out, int shape, P c, int pov, const Tgt& t, int exclude_pk) {
+    PList all;
+    get_targets(all, pov, t, exclude_pk);
+    out.clear();
+    bool base_rule = (shape == SH_FRONT || shape == SH_BEHIND || shape == SH_COLUMN || shape == SH_BORDERING ||
+                      shape == SH_SURROUNDING);
+    for (int i = 0; i < all.n; i++) {
+      P p = all.at(i);
+      if (in_shape(shape, c, pov, p) || (base_rule && p_is_base(p) && t.base)) out.v[out.n++] = all.v[i];
+    }
+    if (shape == SH_FRONT || shape == SH_BEHIND) {
+      // stable sort by y; reverse=True keeps equal keys in original order too (CPython list.sort)
+      bool desc = (shape == SH_FRONT) ? (pov == local()) : (pov == remote());
+      for (int i = 1; i < out.n; i++) {
+        uint8_t k = out.v[i];
+        int ky = p_unpack(k).y;
+        int j = i - 1;
+        while (j >= 0 && (desc ? p_unpack(out.v[j]).y < ky : p_unpack(out.v[j]).y > ky)) {
+          out.v[j + 1] = out.v[j];
+          j--;
+        }
+        out.v[j + 1] = k;
+      }
+    }
+  }
+
+  // numpy RandomState.choice(list) / shuffle(list)
+  MSB_HD MSB_INL int choice_index(int n) { return rng.randint(0, n); }
+  MSB_HD MSB_INL P choice_point(const PList& l) { return l.at(choice_index(l.n)); }
+  MSB_HD MSB_NOINLINE void shuffle(PList& l) {
+    for (int i = l.n - 1; i >= 1; i--) {
+      int j = (int)rng.interval((uint32_t)i);
+      uint8_t tmp = l.v[i];
+      l.v[i] = l.v[j];
+      l.v[j] = tmp;
+    }
+  }
+  // list.sort(key=lambda t: (key(t), random.random()), reverse=rev): random() is called once per
+  // element in list order before sorting; the sort is stable, reverse keeps ties in order.
+  MSB_HD MSB_NOINLINE void sort_by_key_random(PList& l, const int* key, bool rev) {
+    double r[24];
+    int k[24];
+    for (int i = 0; i < l.n; i++) {
+      k[i] = key[i];
+      r[i] = rng.random_sample();
+    }
+    for (int i = 1; i < l.n; i++) {
+      uint8_t pv = l.v[i];
+      int kv = k[i];
+      double rv = r[i];
+      int j = i - 1;
+      while (j >= 0) {
+        bool less = (kv < k[j]) || (kv == k[j] && rv < r[j]);
+        bool greater = (kv > k[j]) || (kv == k[j] && rv > r[j]);
+        if (rev ? !greater : !less) break;
+        l.v[j + 1] = l.v[j];
+        k[j + 1] = k[j];
+        r[j + 1] = r[j];
+        j--;
+      }
+      l.v[j + 1] = pv;
+      k[j + 1] = kv;
+      r[j + 1] = rv;
+    }
+  }
+
+  // ------------------------------------------------------------------------------------------
+  // Deferred triggers: Board.push_trigger / pop_trigger (board.py:46-56) and the wrapper that
+  // Card.__init_subclass__ puts around every overridden activate_ability (card.py:48-62).
+  // ------------------------------------------------------------------------------------------
+  MSB_HD MSB_INL void push_trigger(int e, bool src) {
+    int n = m.ld8(H_TRIG_N);
+    if (n >= TRIG_CAP) {
+      set_fault(FAULT_TRIG_STACK);
+      return;
+    }
+    m.st8(OFF_TRIG + n, e | (src ? 0x80 : 0));
+    m.st8(H_TRIG_N, n + 1);
+  }
+  MSB_HD MSB_INL void pop_trigger() {
+    int n = m.ld8(H_TRIG_N);
+    if (n == 0 || m.ld8(H_RESOLVING)) return;
+    int v = m.ld8(OFF_TRIG + n - 1);
+    m.st8(H_TRIG_N, n - 1);
+    run_ability(v & 0x7f, -1, PK_NONE, (v & 0x80) != 0);
+  }
+  // wrapped activate_ability.  subj >= 0: entity slot.  subj < 0: a spell, spell_card/spell_owner
+  // passed in `spell`.  The trailing pop_trigger() is a tail call in the reference, hence a loop.
+  MSB_HD MSB_NOINLINE void run_ability(int e, int spell, int pos_pk, bool src) {
+    int d = m.ld8(H_DEPTH);
+    if (d >= MAX_DEPTH) {
+      set_fault(FAULT_DEPTH);
+      return;
+    }
+    m.st8(H_DEPTH, d + 1);
+    for (;;) {
+      m.st8(H_RESOLVING, 1);
+      if (e >= 0)
+        ability_entity(e, pos_pk, src);
+      else
+        ability_spell(spell & 0xff, spell >> 8, pos_pk);
+      if (fault()) break;
+      m.st8(H_RESOLVING, 0);
+      int n = m.ld8(H_TRIG_N);
+      if (n == 0) break;
+      int v = m.ld8(OFF_TRIG + n - 1);
+      m.st8(H_TRIG_N, n - 1);
+      e = v & 0x7f;
+      spell = -1;
+      pos_pk = PK_NONE;
+      src = (v & 0x80) != 0;
+    }
+    m.st8(H_DEPTH, d);
+  }
+  // entity.activate_ability(...) as called by the engine: wrapped iff the class overrides it.
+  MSB_HD MSB_INL void activate(int e, int pos_pk, bool src) {
+    if (card_has_ability(e_card(e))) run_ability(e, -1, pos_pk, src);
+  }
+
+  // ------------------------------------------------------------------------------------------
+  // Damage / death / statuses
+  // ------------------------------------------------------------------------------------------
+  // Player.deal_damage / heal, player.py:83-91
+  MSB_HD MSB_INL int player_deal_damage(int order, int amount) {
+    set_pl_base(order, pl_base(order) - amount);
+    return amount;
+  }
+  MSB_HD MSB_INL void player_heal(int order, int amount) { set_pl_base(order, pl_base(order) + amount); }
+
+  // Unit.deal_damage unit.py:205-219 / Structure.deal_damage structure.py:52-63
+  MSB_HD MSB_NOINLINE int entity_deal_damage(int e, int amount, bool pending, bool src) {
+    int s = e_str(e);
+    if (s - amount < 0) amount = s;
+    e_set_dmg(e, amount);
+    s -= amount;
+    e_set_str(e, s);
+    if (!pending && s <= 0) {
+      destroy(e, src);
+    } else if (e_is_unit(e) && card_trigger(e_card(e)) == TR_AFTER_SURVIVING && s > 0) {
+      push_trigger(e, src);
+      pop_trigger();
+    }
+    return amount;
+  }
+  // X.deal_damage(amount, source=...) where X = board.at(point): unit, structure or Player
+  MSB_HD MSB_INL int deal_damage(int who, int amount, bool src) {
+    if (who >= AT_PLAYER) return player_deal_damage(who - AT_PLAYER, amount);
+    if (who < 0) {
+      set_fault(FAULT_PY_EXCEPTION);  // None.deal_damage
+      return 0;
+    }
+    return entity_deal_damage(who, amount, false, src);
+  }
+  MSB_HD MSB_INL void heal(int who, int amount) {
+    if (who >= AT_PLAYER)
+      player_heal(who - AT_PLAYER, amount);
+    else if (who < 0)
+      set_fault(FAULT_PY_EXCEPTION);
+    else
+      e_set_str(who, e_str(who) + amount);
+  }
+  // Unit.destroy unit.py:221-231 / Structure.destroy structure.py:65-69
+  MSB_HD MSB_NOINLINE void destroy(int e, bool src) {
+    if (e_is_unit(e)) {
+      board_set(e_pos(e), -1);
+      m.st8(E_PATHN + e, 0);
+      e_set_dmg(e, e_str(e));
+      if (card_trigger(e_card(e)) == TR_ON_DEATH) {
+        push_trigger(e, src);
+        pop_trigger();
+      }
+      if (fault()) return;
+      recalc_front_after_destroy();
+    } else {
+      e_set_dmg(e, e_str(e));
+      board_set(e_pos(e), -1);
+      recalc_front_after_destroy();
+    }
+  }
+  // status methods, unit.py:239-275.  Calling them on a Structure raises AttributeError.
+  MSB_HD MSB_INL bool need_unit(int e) {
+    if (e < 0 || e >= AT_PLAYER || !e_is_unit(e)) {
+      set_fault(FAULT_PY_EXCEPTION);
+      return false;
+    }
+    return true;
+  }
+  MSB_HD MSB_INL void freeze(int e) {
+    if (need_unit(e)) e_st_add(e, ST_FROZEN);
+  }
+  MSB_HD MSB_INL void poison(int e) {
+    if (!need_unit(e)) return;
+    if (e_st(e, ST_VITALIZED) > 0) e_st_remove(e, ST_VITALIZED);
+    e_st_add(e, ST_POISONED);
+  }
+  MSB_HD MSB_INL void vitalize(int e) {
+    if (!need_unit(e)) return;
+    if (e_st(e, ST_POISONED) > 0) e_st_remove(e, ST_POISONED);
+    e_st_add(e, ST_VITALIZED);
+  }
+  MSB_HD MSB_INL void confuse(int e) {
+    if (need_unit(e)) e_st_add(e, ST_CONFUSED);
+  }
+  MSB_HD MSB_INL void deconfuse(int e) {
+    if (need_unit(e)) e_st_remove(e, ST_CONFUSED);
+  }
+  MSB_HD MSB_INL void disable(int e) {  // unit.py:269-271: only classes that override the ability
+    if (need_unit(e) && card_has_ability(e_card(e))) e_st_add(e, ST_DISABLED);
+  }
+
+  // ------------------------------------------------------------------------------------------
+  // Movement
+  // ------------------------------------------------------------------------------------------
+  // Unit.set_path, unit.py:78-122
+  MSB_HD MSB_NOINLINE void set_path(int e, bool on_play) {
+    P position = e_pos(e);
+    int confused_cached = e_st(e, ST_CONFUSED);
+    int owner = e_owner(e);
+    bool is_local = owner == local();
+    int steps = on_play ? e_mov(e) : 1;
+    uint32_t packed = 0;
+    int n = 0;
+    uint8_t dests[8];
+    int nd = 0;
+    for (int k = 0; k < steps; k++) {
+      P dest{position.x, position.y + (is_local ? -1 : 1)};
+      int nxt = at(dest);
+      if (confused_cached > 0) {
+        int dx;
+        if (position.x == 0)
+          dx = 1;                                  // choice([1]): no draw
+        else if (position.x == 3)
+          dx = -1;                                 // choice([-1]): no draw
+        else
+          dx = rng.randint(0, 2) ? 1 : -1;         // choice([-1, 1])
+        dest = P{position.x + dx, position.y};
+        confused_cached--;
+      } else if (on_play && !e_ff(e) && dest.y != (is_local ? -1 : 5) &&
+                 (nxt == AT_NONE || (nxt < AT_PLAYER && e_owner(nxt) == owner))) {
+        P lp{position.x - 1, position.y}, rp{position.x + 1, position.y};
+        int left = position.x > 0 ? at(lp) : AT_NONE;
+        int right = position.x < 3 ? at(rp) : AT_NONE;
+        bool left_ok = left >= 0 && left < AT_PLAYER && e_owner(left) != owner;
+        bool right_ok = right >= 0 && right < AT_PLAYER && e_owner(right) != owner;
+        int lpk = p_pack(lp), rpk = p_pack(rp);
+        bool lseen = false, rseen = false;
+        for (int i = 0; i < nd; i++) {
+          if (dests[i] == lpk) lseen = true;
+          if (dests[i] == rpk) rseen = true;
+        }
+        if (position.x <= 1) {
+          if (right_ok && !rseen)
+            dest = rp;
+          else if (left_ok && !lseen)
+            dest = lp;
+        } else {
+          if (left_ok && !lseen)
+            dest = lp;
+          else if (right_ok && !rseen)
+            dest = rp;
+        }
+      }
+      // Destinations past the first off-board one are never read (move returns at the base hit);
+      // they are clamped so that they stay encodable.
+      P enc = dest;
+      if (enc.y < -1) enc.y = -1;
+      if (enc.y > 5) enc.y = 5;
+      if (nd < 8) dests[nd++] = (uint8_t)p_pack(enc);
+      if (n < PATH_CAP) {
+        packed |= (uint32_t)p_pack(enc) << (8 * n);
+        n++;
+      } else {
+        set_fault(FAULT_CAPACITY);
+      }
+      position = dest;
+    }
+    m.st32(E_PATH + 4 * e, packed);
+    m.st8(E_PATHN + e, n);
+  }
+
+  // Unit.move, unit.py:124-203
+  MSB_HD MSB_NOINLINE void move(int e) {
+    int d = m.ld8(H_DEPTH);
+    if (d >= MAX_DEPTH) {
+      set_fault(FAULT_DEPTH);
+      return;
+    }
+    m.st8(H_DEPTH, d + 1);
+    move_body(e);
+    m.st8(H_DEPTH, d);
+  }
+  MSB_HD MSB_INL void move_body(int e) {
+    int current_id = (m.ld8(E_MOVEID + e) + 1) & 0xff;
+    m.st8(E_MOVEID + e, current_id);
+    if (phase() == PH_TURN_START) {
+      if (e_st(e, ST_POISONED) > 0)
+        entity_deal_damage(e, 1, false, false);
+      else if (e_st(e, ST_VITALIZED) > 0)
+        e_set_str(e, e_str(e) + 1);
+      if (fault()) return;
+      if (e_frozen(e)) {
+        e_st_remove(e, ST_FROZEN);
+        return;
+      }
+    }
+    if (m.ld8(E_PATHN + e) == 0) return;
+    int trig = e_trigger(e);
+    if (trig == TR_BEFORE_MOVING && !e_disabled(e)) run_ability(e, -1, PK_NONE, true);
+    if (fault()) return;
+    if (e_frozen(e)) return;
+    // `for destination in self.path` iterates the list object bound now (fact #5)
+    int n = m.ld8(E_PATHN + e);
+    uint32_t path = m.ld32(E_PATH + 4 * e);
+    int owner = e_owner(e);  // self.player is re-read by the reference; convert() may change it
+    for (int i = 0; i < n; i++) {
+      P dest = p_unpack((path >> (8 * i)) & 0xff);
+      owner = e_owner(e);
+      if (dest.y < 0 || dest.y > 4) {
+        if (trig == TR_BEFORE_ATTACKING && !e_disabled(e)) run_ability(e, -1, p_pack(dest), true);
+        if (fault()) return;
+        int target = dest.y < 0 ? remote() : local();
+        player_deal_damage(target, e_str(e));
+        if (pl_base(target) > 0) destroy(e, false);
+        return;
+      }
+      int target = at(dest);
+      bool is_attacked = false;
+      if (target != AT_NONE && e_owner(target) == owner && dest.x == e_pos(e).x) return;
+      if (target != AT_NONE && (e_confused(e) || e_owner(target) != owner)) {
+        if (trig == TR_BEFORE_ATTACKING && !e_disabled(e)) run_ability(e, -1, p_pack(dest), true);
+        if (fault()) return;
+        target = at(dest);
+        if (target != AT_NONE) {
+          int target_strength_cached = e_str(target);
+          bool target_pending = e_is_unit(target) && card_trigger(e_card(target)) == TR_ON_DEATH && !e_disabled(target);
+          bool local_pending = trig == TR_ON_DEATH && !e_disabled(e);
+          entity_deal_damage(target, e_str(e), target_pending, false);
+          if (fault()) return;
+          entity_deal_damage(e, target_strength_cached, local_pending, false);
+          if (fault()) return;
+          if (e_str(target) <= 0 && target_pending) destroy(target, false);
+          if (fault()) return;
+          if (e_str(e) <= 0 && local_pending) destroy(e, false);
+          if (fault()) return;
+          is_attacked = true;
+        }
+      }
+      if (current_id != m.ld8(E_MOVEID + e)) return;
+      if (at(dest) == AT_NONE && e_str(e) > 0) {
+        board_set(e_pos(e), -1);
+        board_set(dest, e);
+        int o = e_owner(e);
+        if (pl_front(o) > dest.y) set_pl_front(o, dest.y > 1 ? dest.y : 1);
+        if (is_attacked && trig == TR_AFTER_ATTACKING && !e_disabled(e)) run_ability(e, -1, PK_NONE, true);
+        if (fault()) return;
+        if (e_confused(e)) e_st_remove(e, ST_CONFUSED);
+      }
+    }
+  }
+
+  // Unit.play, unit.py:66-76
+  MSB_HD MSB_NOINLINE void unit_play(int e, P position) {
+    e_set_flag(e, EF_RESOLVING_PLAY, true);
+    board_set(position, e);
+    set_path(e, true);
+    if (card_trigger(e_card(e)) == TR_ON_PLAY) run_ability(e, -1, PK_NONE, true);
+    if (fault()) return;
+    move(e);
+    e_set_flag(e, EF_RESOLVING_PLAY, false);
+  }
+  // Structure.play, structure.py:45-50
+  MSB_HD MSB_NOINLINE void structure_play(int e, P position) {
+    board_set(position, e);
+    if (card_trigger(e_card(e)) == TR_ON_PLAY) run_ability(e, -1, PK_NONE, true);
+  }
+  MSB_HD MSB_INL bool e_resolving_play(int e) const { return (e_flags(e) & EF_RESOLVING_PLAY) != 0; }
+  // Unit.gain_speed, unit.py:277-280
+  MSB_HD MSB_INL void gain_speed(int e, int amount) {
+    int mv = e_mov(e);
+    m.st8(E_MOV + e, mv + amount);
+    set_path(e, e_resolving_play(e));
+    m.st8(E_MOV + e, mv);
+  }
+  // Unit.command, unit.py:282-289
+  MSB_HD MSB_NOINLINE void command(int e) {
+    if (!need_unit(e)) return;
+    bool ff = e_ff(e);
+    e_set_flag(e, EF_FF, true);
+    set_path(e, false);
+    move(e);
+    e_set_flag(e, EF_FF, ff);
+  }
+  // Unit.convert, unit.py:291-293
+  MSB_HD MSB_INL void convert(int e) {
+    int o = e_owner(e);
+    int no = opponent_of(o);
+    e_set_flag(e, EF_OWNER, no != 0);
+    set_path(e, e_resolving_play(e));
+  }
+  // Unit.teleport, unit.py:373-382
+  MSB_HD MSB_NOINLINE void teleport(int e, P dest) {
+    if (at(dest) == AT_NONE) {
+      board_set(e_pos(e), -1);
+      board_set(dest, e);
+      int o = e_owner(e);
+      if (pl_front(o) > dest.y) set_pl_front(o, dest.y > 1 ? dest.y : 1);
+      set_path(e, e_resolving_play(e));
+    }
+  }
+  // Unit.push (away from `from`) unit.py:318-339 and Unit.pull (towards) unit.py:295-316
+  MSB_HD MSB_NOINLINE void push_pull(int e, P from, bool is_push) {
+    if (!need_unit(e)) return;
+    P pos = e_pos(e);
+    int dx = 0, dy = 0;
+    if (from.y < pos.y)
+      dy = is_push ? 1 : -1;
+    else if (from.y > pos.y)
+      dy = is_push ? -1 : 1;
+    else if (from.x < pos.x)
+      dx = is_push ? 1 : -1;
+    else if (from.x > pos.x)
+      dx = is_push ? -1 : 1;
+    if (dx != 0 || dy != 0) {
+      for (;;) {
+        P nx{e_pos(e).x + dx, e_pos(e).y + dy};
+        if (!p_valid(nx)) break;
+        if (at(nx) != AT_NONE) return;  // NB: returns before the front-line update (unit.py:331-332)
+        board_set(e_pos(e), -1);
+        board_set(nx, e);
+      }
+    }
+    int o = e_owner(e);
+    int y = e_pos(e).y;
+    if (pl_front(o) > y) set_pl_front(o, y > 1 ? y : 1);
+  }
+  // Unit.force_attack, unit.py:341-371
+  MSB_HD MSB_NOINLINE void force_attack(int e, P dest) {
+    P pos = e_pos(e);
+    if ((dest.x != pos.x && dest.y != pos.y) || at(dest) == AT_NONE) return;
+    bool vertical = dest.x == pos.x;
+    int fixed = vertical ? pos.x : pos.y;
+    int start = vertical ? pos.y : pos.x;
+    int end = vertical ? dest.y : dest.x;
+    int delta = end > start ? 1 : -1;
+    uint32_t packed = 0;
+    int n = 0;
+    for (int i = start + delta; i != end + delta; i += delta) {
+      P pt = vertical ? P{fixed, i} : P{i, fixed};
+      if (i != end && at(pt) != AT_NONE) return;
+      if (n < PATH_CAP) packed |= (uint32_t)p_pack(pt) << (8 * n);
+      n++;
+    }
+    if (n > PATH_CAP) {
+      set_fault(FAULT_CAPACITY);
+      return;
+    }
+    if (n > 0) {
+      m.st32(E_PATH + 4 * e, packed);
+      m.st8(E_PATHN + e, n);
+      move(e);
+    }
+  }
+  // Board.spawn_token_unit, board.py:298-311 (types always given by the cards)
+  MSB_HD MSB_NOINLINE int spawn_token_unit(int owner, P position, int strength, int unit_type) {
+    int e = new_entity(TOKEN_UNIT_BASE + unit_type, owner, strength, 1, false);
+    if (fault()) return e;
+    board_set(position, e);
+    calculate_front_line(owner);
+    return e;
+  }
+  // Unit.respawn unit.py:384-402 / Structure.respawn structure.py:77-89: a fresh object of the same
+  // class with the given strength is written onto the tile (whatever was there is overwritten).
+  MSB_HD MSB_NOINLINE void respawn(int e, P position, int strength) {
+    int c = e_card(e);
+    int ne;
+    if (c < NUM_CARDS)
+      ne = new_entity(c, e_owner(e), strength, g_cards[c].movement, g_cards[c].ff != 0);
+    else
+      ne = new_entity(c, e_owner(e), strength, e_mov(e), e_ff(e));
+    if (fault()) return;
+    board_set(position, ne);
+  }
+
+  // ------------------------------------------------------------------------------------------
+  // Player: hand / deck (player.py:46-81)
+  // ------------------------------------------------------------------------------------------
+  // Card equality used by list.remove: Unit/Structure compare (card_id, player, position)
+  // (unit.py:25-26, structure.py:18-19); Spells compare identity (card.py:22-23).
+  MSB_HD MSB_INL bool card_eq_by_id(int card) const { return card >= NUM_CARDS || g_cards[card].kind != KIND_SPELL; }
+
+  // Player.draw, player.py:46-52: numpy choice(deck, size=1, p=w/sum(w))
+  MSB_HD MSB_NOINLINE void draw(int o, int amount) {
+    for (int k = 0; k < amount; k++) {
+      int n = pl_deck_n(o);
+      if (n == 0) {
+        set_fault(FAULT_PY_EXCEPTION);  // choice over an empty deck raises
+        return;
+      }
+      double sum = 0.0;  // Python sum(): 0 + w0 + w1 ... left to right
+      for (int i = 0; i < n; i++) sum = sum + deck_w(o, i);
+      double cdf[DECK_CAP];
+      double acc = 0.0;
+      for (int i = 0; i < n; i++) {
+        double p = deck_w(o, i) / sum;
+        acc = (i == 0) ? p : acc + p;   // ndarray.cumsum: sequential
+        cdf[i] = acc;
+      }
+      double last = cdf[n - 1];
+      for (int i = 0; i < n; i++) cdf[i] = cdf[i] / last;
+      double u = rng.random_sample();
+      int idx = 0;  // searchsorted(side='right')
+      while (idx < n && cdf[idx] <= u) idx++;
+      if (idx >= n) {
+        set_fault(FAULT_PY_EXCEPTION);
+        return;
+      }
+      int card = deck_card(o, idx), cost = deck_cost(o, idx), fl = deck_flags(o, idx);
+      set_deck_w(o, idx, 1.0);
+      int hn = pl_hand_n(o);
+      if (hn >= HAND_CAP) {
+        set_fault(FAULT_CAPACITY);
+        return;
+      }
+      m.st8(pl(o, P_HAND + 4 * hn), card);
+      m.st8(pl(o, P_HAND + 4 * hn + 1), cost);
+      m.st8(pl(o, P_HAND + 4 * hn + 2), fl);
+      m.st8(pl(o, P_HAND_N), hn + 1);
+      // deck.remove(choice): first EQUAL element
+      int j = idx;
+      if (card_eq_by_id(card))
+        for (int i = 0; i < idx; i++)
+          if (deck_card(o, i) == card) {
+            j = i;
+            break;
+          }
+      for (int i = j; i + 1 < n; i++) {
+        m.st32(pl(o, P_DECK + 4 * i), m.ld32(pl(o, P_DECK + 4 * (i + 1))));
+        set_deck_w(o, i, deck_w(o, i + 1));
+      }
+      m.st8(pl(o, P_DECK_N), n - 1);
+    }
+  }
+  // Player.fill_hand, player.py:54-55
+  MSB_HD MSB_INL void fill_hand(int o) {
+    int need = 4 - pl_hand_n(o);
+    if (need > 0) draw(o, need);
+  }
+  // Player.discard, player.py:57-66 (reweight: w*1.6+100 for every deck card)
+  MSB_HD MSB_NOINLINE void discard(int o, int hand_index) {
+    int n = pl_deck_n(o);
+    for (int i = 0; i < n; i++) set_deck_w(o, i, deck_w(o, i) * 1.6 + 100);
+    int card = hand_card(o, hand_index), cost = hand_cost(o, hand_index), fl = hand_flags(o, hand_index);
+    // hand.remove(target): first equal
+    int j = hand_index;
+    if (card_eq_by_id(card))
+      for (int i = 0; i < hand_index; i++)
+        if (hand_card(o, i) == card) {
+          j = i;
+          break;
+        }
+    int hn = pl_hand_n(o);
+    for (int i = j; i + 1 < hn; i++) m.st32(pl(o, P_HAND + 4 * i), m.ld32(pl(o, P_HAND + 4 * (i + 1))));
+    m.st8(pl(o, P_HAND_N), hn - 1);
+    if (!(fl & CF_SINGLE_USE)) {
+      if (n >= DECK_CAP) {
+        set_fault(FAULT_CAPACITY);
+        return;
+      }
+      m.st8(pl(o, P_DECK + 4 * n), card);
+      m.st8(pl(o, P_DECK + 4 * n + 1), cost);
+      m.st8(pl(o, P_DECK + 4 * n + 2), fl);
+      m.st8(pl(o, P_DECK + 4 * n + 3), 0);
+      set_deck_w(o, n, 1.0);  // hand cards always carry weight 1 (player.py:50)
+      m.st8(pl(o, P_DECK_N), n + 1);
+    }
+  }
+  // Board.add_to_history, board.py:324-325 (only the last four are observable)
+  MSB_HD MSB_INL void add_history(int owner, int card) {
+    int n = m.ld8(H_HIST_N);
+    if (n < 4) {
+      m.st8(H_HIST + 2 * n, owner);
+      m.st8(H_HIST + 2 * n + 1, card);
+      m.st8(H_HIST_N, n + 1);
+    } else {
+      for (int i = 0; i < 3; i++) {
+        m.st8(H_HIST + 2 * i, m.ld8(H_HIST + 2 * (i + 1)));
+        m.st8(H_HIST + 2 * i + 1, m.ld8(H_HIST + 2 * (i + 1) + 1));
+      }
+      m.st8(H_HIST + 6, owner);
+      m.st8(H_HIST + 7, card);
+    }
+  }
+  // Player.play, player.py:68-77.  has_pos=false <=> position None
+  MSB_HD MSB_NOINLINE void player_play(int o, int index, P position, bool has_pos) {
+    int card = hand_card(o, index), fl = hand_flags(o, index);
+    add_history(o, card);
+    discard(o, index);
+    if (fault()) return;
+    const CardInfo& ci = g_cards[card];
+    if (ci.kind == KIND_UNIT) {
+      int e = new_entity(card, o, ci.strength, ci.movement, (fl & CF_FF) != 0);   // target.copy()
+      if (fault()) return;
+      if (!has_pos) {
+        set_fault(FAULT_PY_EXCEPTION);
+        return;
+      }
+      unit_play(e, position);
+    } else if (ci.kind == KIND_STRUCT) {
+      int e = new_entity(card, o, ci.strength, 0, false);
+      if (fault()) return;
+      if (!has_pos) {
+        set_fault(FAULT_PY_EXCEPTION);
+        return;
+      }
+      structure_play(e, position);
+    } else {
+      // Spell.play, spell.py:22-24
+      bool go = true;
+      if (ci.tgt.has) {
+        Tgt t = mk_tgt(ci.tgt);
+        PList l;
+        get_targets(l, cp(), t, PK_NONE);
+        go = has_pos && l.has(position);
+        // `None in [Point...]` evaluates Point.__eq__(None) -> AttributeError when the list is non-empty
+        if (!has_pos && l.n > 0) {
+          set_fault(FAULT_PY_EXCEPTION);
+          return;
+        }
+      }
+      if (go) run_ability(-1, card | (o << 8), has_pos ? p_pack(position) : PK_NONE, true);
+    }
+  }
+  // Player.cycle, player.py:79-81
+  MSB_HD MSB_INL void cycle(int o, int hand_index) {
+    discard(o, hand_index);
+    if (fault()) return;
+    draw(o, 1);
+  }
+
+  // ------------------------------------------------------------------------------------------
+  // Turn structure
+  // ------------------------------------------------------------------------------------------
+  // Board.flip, board.py:94-115.  H_TOPLAY has already been toggled by the caller, which swaps
+  // local/remote; entity.player keeps the same PlayerOrder through the "ownership swap".
+  MSB_HD MSB_NOINLINE void flip() {
+    set_pl_front(0, 4 - pl_front(0));
+    set_pl_front(1, 4 - pl_front(1));
+    for (int t = 0; t < 10; t++) {
+      int a = board_at(t), b = board_at(19 - t);
+      board_put(t, b);
+      board_put(19 - t, a);
+    }
+    for (int t = 0; t < 20; t++) {
+      int s = board_at(t);
+      if (s != SLOT_NONE) m.st8(E_POS + s, t);
+    }
+  }
+  // Board.to_next_turn, board.py:117-145
+  MSB_HD MSB_NOINLINE void to_next_turn() {
+    m.st8(H_PHASE, PH_TURN_END);
+    int ender = cp();
+    fill_hand(ender);
+    if (fault()) return;
+    // No card in the reference has a TURN_END trigger (structure.py:8 default is [TURN_START],
+    // b305 is [ON_PLAY]); the TURN_END loop (board.py:121-123) never fires an ability.
+    calculate_front_line(local());
+    calculate_front_line(remote());
+    m.st16(pl(ender, P_MAXMANA), pl_maxmana(ender) + 1);
+    set_pl_mana(0, pl_maxmana(0));
+    set_pl_mana(1, pl_maxmana(1));
+    m.st8(H_PHASE, PH_TURN_START);
+    int ncp = (ender == local()) ? remote() : local();
+    m.st8(H_CP, ncp);
+    m.st8(pl(ncp, P_FLAGS), m.ld8(pl(ncp, P_FLAGS)) | 3);
+    // snapshots of entity objects (fact #6)
+    uint8_t snap[20];
+    int ns = 0;
+    {
+      PList l;
+      get_targets(l, ncp, mk_tgt(TK_STRUCTURE, TS_FRIENDLY), PK_NONE);
+      for (int i = 0; i < l.n; i++) snap[ns++] = (uint8_t)at(l.at(i));
+    }
+    for (int i = 0; i < ns; i++) {
+      int s = snap[i];
+      // structure.is_at_turn_start: token structures and b001 run the empty base ability
+      if (card_trigger(e_card(s)) == TR_TURN_START) run_ability(s, -1, m.ld8(E_POS + s) /*unused*/, true);
+      if (fault()) return;
+    }
+    ns = 0;
+    {
+      PList l;
+      get_targets(l, ncp, mk_tgt(TK_UNIT, TS_FRIENDLY), PK_NONE);
+      for (int i = 0; i < l.n; i++) snap[ns++] = (uint8_t)at(l.at(i));
+    }
+    for (int i = 0; i < ns; i++) {
+      set_path(snap[i], false);
+      move(snap[i]);
+      if (fault()) return;
+    }
+    m.st8(H_PHASE, PH_PLAY);
+  }
+
+  // Stormbound.have_winner, games/stormbound.py:560-561 (strict: a base at exactly 0 is alive)
+  MSB_HD MSB_INL bool have_winner() const { return pl_base(0) < 0 || pl_base(1) < 0; }
+
+  // Stormbound.legal_actions + Action.to_int, games/stormbound.py:528-557, 258-290 -> 156-bit mask
+  MSB_HD MSB_NOINLINE void legal_mask(uint64_t mask[3]) {
+    mask[0] = mask[1] = mask[2] = 0;
+    int lo = local();
+    int hn = pl_hand_n(lo), mana = pl_mana(lo), fl = pl_front(lo);
+    bool any_play = false;
+    for (int c = 0; c < hn; c++) {
+      if (hand_cost(lo, c) > mana) continue;
+      int card = hand_card(lo, c);
+      const CardInfo& ci = g_cards[card];
+      if (ci.kind != KIND_SPELL) {
+        for (int y = 4; y >= fl; y--)
+          for (int x = 0; x < 4; x++)
+            if (board_at(y * 4 + x) == SLOT_NONE) {
+              // to_int only enumerates y=4..1; anything else stays 155 (games/stormbound.py:262-271)
+              int a = (y >= 1) ? 16 * c + (4 - y) * 4 + x : 155;
+              if (a < 156) mask[a >> 6] |= 1ull << (a & 63);
+              any_play = true;
+            }
+      } else if (!ci.tgt.has) {
+        int a = 64 + 21 * c;
+        if (a < 156) mask[a >> 6] |= 1ull << (a & 63);
+        any_play = true;
+      } else {
+        Tgt t = mk_tgt(ci.tgt);
+        PList l;
+        get_targets(l, cp(), t, PK_NONE);
+        for (int i = 0; i < l.n; i++) {
+          P p = l.at(i);
+          int a = p_valid(p) ? 65 + 21 * c + (4 - p.y) * 4 + p.x : 155;
+          if (a < 156) mask[a >> 6] |= 1ull << (a & 63);
+          any_play = true;
+        }
+      }
+    }
+    if (m.ld8(pl(lo, P_FLAGS)) & 1)
+      for (int c = 0; c < hn; c++) {
+        int a = 148 + c;
+        mask[a >> 6] |= 1ull << (a & 63);
+      }
+    if (!any_play) mask[2] |= 1ull << (155 & 63);
+  }
+
+  // Stormbound.step, games/stormbound.py:318-373 (without the observation; see features.h).
+  // The caller guarantees `action` is in legal_actions().  reward/done as the reference returns.
+  MSB_HD MSB_NOINLINE void step(int action, int* reward, int* done) {
+    begin_step();
+    int lo = local();
+    if (action < 64) {
+      int ci = action >> 4, idx = action & 15;
+      P pos{idx & 3, 4 - (idx >> 2)};
+      set_pl_mana(lo, pl_mana(lo) - hand_cost(lo, ci));
+      player_play(lo, ci, pos, true);
+    } else if (action < 148) {
+      int ci = (action - 64) / 21, idx = (action - 64) % 21;
+      // The countdown executes at the idx-th tile of y=4..0,x=0..3 -- one tile after the one
+      // Action.to_int encoded (fact #2); idx==20 falls off the loop: nothing happens at all.
+      if (idx < 20) {
+        P pos{idx & 3, 4 - (idx >> 2)};
+        bool targeted = g_cards[hand_card(lo, ci)].tgt.has != 0;
+        set_pl_mana(lo, pl_mana(lo) - hand_cost(lo, ci));
+        player_play(lo, ci, pos, targeted);
+      }
+    } else if (action < 152) {
+      cycle(lo, action - 148);
+      m.st8(pl(lo, P_FLAGS), m.ld8(pl(lo, P_FLAGS)) & ~1);
+    } else if (action < 155) {
+      int ci = action - 151;
+      uint32_t a = m.ld32(pl(lo, P_HAND + 4 * ci)), b = m.ld32(pl(lo, P_HAND));
+      m.st32(pl(lo, P_HAND + 4 * ci), b);
+      m.st32(pl(lo, P_HAND), a);
+      m.st8(pl(lo, P_FLAGS), m.ld8(pl(lo, P_FLAGS)) & ~2);
+    }
+    if (fault()) return;
+    // done = have_winner() or len(legal_actions()) == 0; legal_actions() is never empty (PASS)
+    if (done) *done = have_winner() ? 1 : 0;
+    if (reward) *reward = pl_base(remote()) <= 0 ? 1 : 0;
+    if (action == 155) {
+      m.st8(H_TOPLAY, lo ^ 1);
+      flip();
+      to_next_turn();
+    }
+    if (rng.overrun) set_fault(FAULT_RNG_OVERRUN);
+  }
+
+  // Game construction: Stormbound.__init__ / Player.__init__ (games/stormbound.py:293-304,
+  // player.py:13-37).  deck0/deck1: 12 card indices in constructor order.
+  MSB_HD MSB_NOINLINE void init_game(const uint8_t* deck0, const uint8_t* deck1, int faction0, int faction1) {
+    for (int w = 0; w < STATE_WORDS; w++) m.st32(4 * w, 0);
+    for (int t = 0; t < 20; t++) board_put(t, SLOT_NONE);
+    for (int e = 0; e < NUM_ENT; e++) m.st8(E_CARD + e, CARD_NONE);
+    for (int i = 0; i < 4; i++) {
+      m.st8(H_HIST + 2 * i, 0xff);
+      m.st8(H_HIST + 2 * i + 1, 0xff);
+    }
+    m.st8(H_PHASE, PH_PLAY);
+    for (int o = 0; o < 2; o++) {
+      const uint8_t* deck = o == 0 ? deck0 : deck1;
+      m.st16(pl(o, P_BASE), 20);
+      m.st16(pl(o, P_MAXMANA), o == 0 ? 3 : 4);
+      m.st16(pl(o, P_MANA), o == 0 ? 3 : 4);
+      m.st8(pl(o, P_FRONT), o == 0 ? 4 : 0);
+      m.st8(pl(o, P_FLAGS), 3);
+      m.st8(pl(o, P_FACTION), o == 0 ? faction0 : faction1);
+      uint8_t d[DECK_CAP];
+      for (int i = 0; i < DECK_CAP; i++) d[i] = deck[i];
+      for (int i = DECK_CAP - 1; i >= 1; i--) {  // random.shuffle(self.deck)
+        int j = (int)rng.interval((uint32_t)i);
+        uint8_t tmp = d[i];
+        d[i] = d[j];
+        d[j] = tmp;
+      }
+      double w = 1.0;
+      for (int i = 0; i < DECK_CAP; i++) {
+        if (i > 0) w = w * 1.6 + 100;
+        m.st8(pl(o, P_DECK + 4 * i), d[i]);
+        m.st8(pl(o, P_DECK + 4 * i + 1), g_cards[d[i]].cost);
+        m.st8(pl(o, P_DECK + 4 * i + 2), g_cards[d[i]].ff ? CF_FF : 0);
+        set_deck_w(o, i, w);
+      }
+      m.st8(pl(o, P_DECK_N), DECK_CAP);
+      fill_hand(o);
+    }
+    if (rng.overrun) set_fault(FAULT_RNG_OVERRUN);
+  }
+
+  // ------------------------------------------------------------------------------------------
+  // Card abilities (cards/*.py).  Dispatch by card index = the device-side opcode table.
+  // ------------------------------------------------------------------------------------------
+#include "abilities.inc"
+#include "observe.inc"
+};
+
+}  // namespace msb

@@ -1,0 +1,153 @@
+// Per-game state record: byte layout + the two memory accessors the rules core runs on.
+//
+// One record = STATE_BYTES bytes, every field naturally aligned.  In HBM a batch of games is
+// stored word-interleaved (word w of game g at  w*stride + g), so that a wavefront reading the
+// same field of 64 consecutive games issues one coalesced 256-byte access.  Inside a kernel a
+// record lives in LDS, again word-interleaved across the lanes of the wave (word w of lane l at
+// w*LANES + l): all lanes touching the same field hit 64 different banks, no conflicts
+// (MI355X_MICROARCH.md, LDS: ds_read_b32 is serviced as two conflict-free 32-lane groups).
+//
+// What the fields restate (reference file:line):
+//   header      games/stormbound.py:304 (player), board.py:20-25 (current_player, history, triggers,
+//               is_resolving_trigger, phase)
+//   board[20]   board.py:17  5x4 grid of object references -> entity slot ids (0xFF = None)
+//   players[2]  player.py:13-37  indexed by PlayerOrder (FIRST=0, SECOND=1), not by local/remote
+//   entities    unit.py:8-23 / structure.py:8-16 object attributes.  Slots have identity: the
+//               reference iterates snapshots of entity OBJECTS (board.py:141-143) and keeps dead
+//               units on its trigger stack, so a tile grid alone cannot reproduce it.
+#pragma once
+#include "msb_base.h"
+
+namespace msb {
+
+constexpr int NUM_ENT = 28;    // 20 tiles + 8 transient (dead / displaced / spawned this step)
+constexpr int HAND_CAP = 5;    // 4, transiently 5 (b305 returns itself to hand)
+constexpr int DECK_CAP = 12;   // 12-card decks; ua20's extra single-use cards need a larger build
+constexpr int TRIG_CAP = 20;
+constexpr int PATH_CAP = 4;    // max movement among the cards (u069=4; gain_speed gives <= 3)
+constexpr int SLOT_NONE = 0xFF;
+
+// ---- header -----------------------------------------------------------------------------------
+constexpr int H_TOPLAY = 0;     // 0 if Stormbound.player == 1 else 1; also the order of board.local
+constexpr int H_FAULT = 1;
+constexpr int H_HIST_N = 2;     // min(4, len(board.history))
+constexpr int H_TRIG_N = 3;
+constexpr int H_RESOLVING = 4;  // board.is_resolving_trigger
+constexpr int H_PHASE = 5;
+constexpr int H_DEPTH = 6;      // recursion guard (build limit)
+constexpr int H_CP = 7;         // order of board.current_player
+constexpr int H_HIST = 8;       // 4 x {owner, card}; oldest first
+constexpr int H_USED = 16;      // u32: entity slots referenced since the start of this step
+constexpr int H_STEPS = 20;     // u16 committed decisions so far (rollout bookkeeping), u16 pad
+constexpr int OFF_BOARD = 24;   // 20 x u8 slot
+constexpr int OFF_TRIG = 44;    // TRIG_CAP x u8 (slot | has_source<<7)
+constexpr int OFF_PL = 64;
+
+// ---- player -------------------------------------------------------------------------------------
+constexpr int P_BASE = 0;       // i16 Player.strength
+constexpr int P_MANA = 2;       // i16 current_mana
+constexpr int P_MAXMANA = 4;    // i16 max_mana
+constexpr int P_FRONT = 6;      // u8 front_line
+constexpr int P_FLAGS = 7;      // b0 replacable, b1 leftmost_movable
+constexpr int P_FACTION = 8;
+constexpr int P_HAND_N = 9;
+constexpr int P_DECK_N = 10;
+constexpr int P_HAND = 12;                      // HAND_CAP x {card, cost, flags, pad}
+constexpr int P_DECK = P_HAND + 4 * HAND_CAP;   // DECK_CAP x {card, cost, flags, pad}
+constexpr int P_WEIGHT = (P_DECK + 4 * DECK_CAP + 7) & ~7;  // DECK_CAP x f64
+constexpr int PL_SIZE = P_WEIGHT + 8 * DECK_CAP;
+static_assert((OFF_PL % 8) == 0 && (PL_SIZE % 8) == 0, "f64 alignment");
+constexpr int CF_SINGLE_USE = 1, CF_FF = 2;     // card-instance flags (hand/deck entries)
+
+// ---- entities (field arrays) ------------------------------------------------------------------
+constexpr int OFF_ENT = OFF_PL + 2 * PL_SIZE;
+constexpr int E_CARD = OFF_ENT;                 // u8[NUM_ENT] card index (CARD_NONE = free)
+constexpr int E_FLAGS = E_CARD + NUM_ENT;       // u8 b0 owner order, b1 fixedly_forward, b2 resolving_play
+constexpr int E_POS = E_FLAGS + NUM_ENT;        // u8 recorded position y*4+x
+constexpr int E_MOV = E_POS + NUM_ENT;          // u8 movement
+constexpr int E_ST = E_MOV + NUM_ENT;           // u8[5][NUM_ENT] status multiset counts
+constexpr int E_MOVEID = E_ST + 5 * NUM_ENT;    // u8 move_id (mod 256)
+constexpr int E_PATHN = E_MOVEID + NUM_ENT;     // u8 len(path)
+constexpr int E_STR = (E_PATHN + NUM_ENT + 1) & ~1;   // i16 strength
+constexpr int E_DMG = E_STR + 2 * NUM_ENT;      // i16 damage_taken
+constexpr int E_PATH = (E_DMG + 2 * NUM_ENT + 3) & ~3;  // u32 packed path (PATH_CAP bytes)
+constexpr int STATE_BYTES = (E_PATH + 4 * NUM_ENT + 7) & ~7;
+constexpr int STATE_WORDS = STATE_BYTES / 4;
+constexpr int EF_OWNER = 1, EF_FF = 2, EF_RESOLVING_PLAY = 4;
+
+// ---- accessors ----------------------------------------------------------------------------------
+// Host / flat: the record is a contiguous byte array.
+struct FlatMem {
+  uint8_t* p;
+  MSB_HD MSB_INL int ld8(int o) const { return p[o]; }
+  MSB_HD MSB_INL void st8(int o, int v) { p[o] = (uint8_t)v; }
+  MSB_HD MSB_INL int ld16(int o) const { return *(const int16_t*)(p + o); }
+  MSB_HD MSB_INL void st16(int o, int v) { *(int16_t*)(p + o) = (int16_t)v; }
+  MSB_HD MSB_INL uint32_t ld32(int o) const { return *(const uint32_t*)(p + o); }
+  MSB_HD MSB_INL void st32(int o, uint32_t v) { *(uint32_t*)(p + o) = v; }
+  MSB_HD MSB_INL double ldf(int o) const { return *(const double*)(p + o); }
+  MSB_HD MSB_INL void stf(int o, double v) { *(double*)(p + o) = v; }
+};
+
+// Word-interleaved: word w of this record is at base[w * stride]; `base` already points at this
+// record's column (lane or game).  Used for LDS (stride = lanes per wave) and HBM (stride = batch).
+struct StridedMem {
+  uint32_t* base;
+  int stride;
+  MSB_HD MSB_INL uint8_t* b(int o) const { return (uint8_t*)(base + (o >> 2) * stride) + (o & 3); }
+  MSB_HD MSB_INL int ld8(int o) const { return *b(o); }
+  MSB_HD MSB_INL void st8(int o, int v) { *b(o) = (uint8_t)v; }
+  MSB_HD MSB_INL int ld16(int o) const { return *(const int16_t*)b(o); }
+  MSB_HD MSB_INL void st16(int o, int v) { *(int16_t*)b(o) = (int16_t)v; }
+  MSB_HD MSB_INL uint32_t ld32(int o) const { return base[(o >> 2) * stride]; }
+  MSB_HD MSB_INL void st32(int o, uint32_t v) { base[(o >> 2) * stride] = v; }
+  MSB_HD MSB_INL double ldf(int o) const {
+    union { uint32_t u[2]; double d; } x;
+    x.u[0] = ld32(o);
+    x.u[1] = ld32(o + 4);
+    return x.d;
+  }
+  MSB_HD MSB_INL void stf(int o, double v) {
+    union { uint32_t u[2]; double d; } x;
+    x.d = v;
+    st32(o, x.u[0]);
+    st32(o + 4, x.u[1]);
+  }
+};
+
+#if defined(__HIPCC__)
+// Device-only forms with explicit address spaces, so that hipcc emits ds_read/ds_write (LDS) and
+// global_load/global_store (HBM) instead of flat_* instructions behind non-inlined calls.
+#define MSB_AS_LDS __attribute__((address_space(3)))
+#define MSB_AS_GLB __attribute__((address_space(1)))
+struct LdsMem {
+  MSB_AS_LDS uint32_t* base;   // this lane's column
+  int stride;                  // lanes per wave sharing the block
+  MSB_HD MSB_INL MSB_AS_LDS uint8_t* b(int o) const { return (MSB_AS_LDS uint8_t*)(base + (o >> 2) * stride) + (o & 3); }
+  MSB_HD MSB_INL int ld8(int o) const { return *b(o); }
+  MSB_HD MSB_INL void st8(int o, int v) { *b(o) = (uint8_t)v; }
+  MSB_HD MSB_INL int ld16(int o) const { return *(MSB_AS_LDS const int16_t*)b(o); }
+  MSB_HD MSB_INL void st16(int o, int v) { *(MSB_AS_LDS int16_t*)b(o) = (int16_t)v; }
+  MSB_HD MSB_INL uint32_t ld32(int o) const { return base[(o >> 2) * stride]; }
+  MSB_HD MSB_INL void st32(int o, uint32_t v) { base[(o >> 2) * stride] = v; }
+  MSB_HD MSB_INL double ldf(int o) const {
+    union { uint32_t u[2]; double d; } x;
+    x.u[0] = ld32(o);
+    x.u[1] = ld32(o + 4);
+    return x.d;
+  }
+  MSB_HD MSB_INL void stf(int o, double v) {
+    union { uint32_t u[2]; double d; } x;
+    x.d = v;
+    st32(o, x.u[0]);
+    st32(o + 4, x.u[1]);
+  }
+};
+#endif
+
+template <class A, class B>
+MSB_HD MSB_INL void copy_state(A& dst, const B& src) {
+  for (int w = 0; w < STATE_WORDS; w++) dst.st32(w * 4, src.ld32(w * 4));
+}
+
+}  // namespace msb

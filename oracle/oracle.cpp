@@ -1,0 +1,302 @@
+// oracle/oracle.cpp -- CPU replay oracle.  TEST INFRASTRUCTURE, NOT PRODUCT.
+//
+// Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg load this library; the
+// product (monsoon_amd/, libmonsoon_hip.so) never links, imports or calls it and has no CPU path.
+//
+// What it is: the host compilation (g++) of the rules core in monsoon_amd/csrc/ -- rules.h,
+// abilities.inc, observe.inc, mt19937.h -- which restates the reference engine function by
+// function (each cites its reference file:line), run scalar, one game at a time, with the
+// state in a plain byte array.  It is pinned to the Python reference by the golden vectors under
+// tests/golden/ (generated in the build container by oracle/pyref/gen_golden.py from
+// /root/reference itself) and by the live differential fuzzer oracle/pyref/difffuzz.py.
+// The GPU tests compare the HIP kernels against BOTH this oracle and those golden vectors, so a
+// bug shared by the two builds of the rules core still has to get past the reference's own outputs.
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "../monsoon_amd/csrc/canon.h"
+
+using namespace msb;
+
+namespace {
+
+struct Game {
+  alignas(8) uint8_t st[STATE_BYTES];
+  uint32_t mt[MT_N];
+  uint32_t out[2][MT_N];
+  int cur;        // which of out[] is the current block
+  uint32_t pos;   // cursor in the current block, 0..624
+  int result;     // -2 running, -1 draw, 0 P1 win, 1 P2 win
+  int steps;      // committed decisions
+  uint64_t lookahead_steps;
+};
+
+struct Oracle {
+  std::vector<Game> games;
+};
+
+void refill(Game& g, int which) {
+  mt_twist(g.mt);
+  for (int i = 0; i < MT_N; i++) g.out[which][i] = mt_temper(g.mt[i]);
+}
+
+void seed_game(Game& g, uint32_t seed) {
+  mt_seed(g.mt, seed);
+  g.cur = 0;
+  g.pos = 0;
+  refill(g, 0);
+  refill(g, 1);
+}
+
+RngView view(const Game& g) { return RngView{g.out[g.cur], g.out[g.cur ^ 1], g.pos, 0}; }
+
+// advance the game's stream to a view's cursor
+void commit_rng(Game& g, const RngView& v) {
+  g.pos = v.pos;
+  if (g.pos >= (uint32_t)MT_N) {
+    g.pos -= MT_N;
+    int old = g.cur;
+    g.cur ^= 1;
+    refill(g, old);
+  }
+}
+
+Engine<FlatMem> engine(Game& g) {
+  Engine<FlatMem> e;
+  e.m.p = g.st;
+  e.rng = view(g);
+  return e;
+}
+
+uint32_t peek(const Game& g) {
+  RngView v = view(g);
+  return v.next_u32();
+}
+
+int game_result(Engine<FlatMem>& e) {
+  // SURVEY §8c rollout contract (mirrors evo/fitness.py:160-166 scoring)
+  int b0 = e.pl_base(0), b1 = e.pl_base(1);
+  if (b1 < 0 && b0 >= 0) return 0;
+  if (b0 < 0 && b1 >= 0) return 1;
+  return -1;
+}
+
+// One decision of HeuristicAgent.select_action (evo/heuristic_agent.py:53-80): scores[a] for every
+// legal action (ascending = the sorted legal list), argmax = first maximum.
+int decide(Game& g, const double* w, double* scores_out, int* n_legal_out, uint64_t* mask_out) {
+  Engine<FlatMem> e = engine(g);
+  uint64_t mask[3];
+  e.legal_mask(mask);
+  if (mask_out) memcpy(mask_out, mask, sizeof(mask));
+  double fb[10];
+  bool before_raises = e.observation_raises();
+  if (!before_raises) e.features(fb);
+  int best = -1;
+  double best_score = 0.0;
+  int n_legal = 0;
+  for (int a = 0; a < 156; a++) {
+    if (!(mask[a >> 6] >> (a & 63) & 1)) {
+      if (scores_out) scores_out[a] = NAN;
+      continue;
+    }
+    n_legal++;
+    Game c = g;  // copy.deepcopy(self.game), evo/game_adapter.py:284 (stream included)
+    Engine<FlatMem> ce = engine(c);
+    int r, d;
+    ce.step(a, &r, &d);
+    g.lookahead_steps++;
+    double s = 0.0;  // except Exception -> 0.0 (evo/heuristic_agent.py:48-51)
+    if (!ce.fault() && !before_raises && !ce.observation_raises()) {
+      double fa[10];
+      ce.features(fa);
+      s = Engine<FlatMem>::action_score(w, fb, fa);
+    }
+    if (scores_out) scores_out[a] = s;
+    if (best < 0 || s > best_score) {
+      best = a;
+      best_score = s;
+    }
+  }
+  if (n_legal_out) *n_legal_out = n_legal;
+  return best;
+}
+
+// adapter = adapter.apply_action(action): commit.  Returns the fault code of the step.
+int commit(Game& g, int action) {
+  Engine<FlatMem> e = engine(g);
+  int r, d;
+  e.step(action, &r, &d);
+  int f = e.fault();
+  if (!f && e.observation_raises()) f = FAULT_INT_CARD;  // step() returns get_observation()
+  commit_rng(g, e.rng);
+  g.steps++;
+  return f;
+}
+
+}  // namespace
+
+extern "C" {
+
+void* orc_create(int n) {
+  Oracle* o = new Oracle();
+  o->games.resize(n);
+  for (auto& g : o->games) {
+    memset(&g, 0, sizeof(g));
+    g.result = -2;
+  }
+  return o;
+}
+void orc_destroy(void* h) { delete (Oracle*)h; }
+int orc_state_bytes() { return STATE_BYTES; }
+
+int orc_reset(void* h, int gi, uint32_t seed, const uint8_t* deck0, const uint8_t* deck1, int f0, int f1) {
+  Game& g = ((Oracle*)h)->games[gi];
+  seed_game(g, seed);
+  g.result = -2;
+  g.steps = 0;
+  g.lookahead_steps = 0;
+  Engine<FlatMem> e = engine(g);
+  e.init_game(deck0, deck1, f0, f1);
+  commit_rng(g, e.rng);
+  return e.fault();
+}
+
+void orc_legal(void* h, int gi, uint64_t* mask3) {
+  Game& g = ((Oracle*)h)->games[gi];
+  Engine<FlatMem> e = engine(g);
+  e.legal_mask(mask3);
+}
+
+// Stormbound.step (games/stormbound.py:318-373).  Returns the fault code (0 = ok).
+int orc_step(void* h, int gi, int action, int* reward, int* done) {
+  Game& g = ((Oracle*)h)->games[gi];
+  Engine<FlatMem> e = engine(g);
+  e.step(action, reward, done);
+  int f = e.fault();
+  commit_rng(g, e.rng);
+  g.steps++;
+  return f;
+}
+
+int orc_observe(void* h, int gi, int32_t* out540) {
+  Game& g = ((Oracle*)h)->games[gi];
+  Engine<FlatMem> e = engine(g);
+  if (e.observation_raises()) return 1;
+  e.observe(out540);
+  return 0;
+}
+
+int orc_features(void* h, int gi, double* f10) {
+  Game& g = ((Oracle*)h)->games[gi];
+  Engine<FlatMem> e = engine(g);
+  if (e.observation_raises()) return 1;
+  e.features(f10);
+  return 0;
+}
+
+int orc_canon(void* h, int gi, uint8_t* buf) {
+  Game& g = ((Oracle*)h)->games[gi];
+  Engine<FlatMem> e = engine(g);
+  return canon_record(e, peek(g), buf);
+}
+uint64_t orc_canon_hash(void* h, int gi) {
+  uint8_t buf[CANON_MAX];
+  int n = orc_canon(h, gi, buf);
+  return fnv1a64(buf, n);
+}
+
+int orc_have_winner(void* h, int gi) {
+  Game& g = ((Oracle*)h)->games[gi];
+  Engine<FlatMem> e = engine(g);
+  return e.have_winner() ? 1 : 0;
+}
+int orc_to_play(void* h, int gi) { return ((Oracle*)h)->games[gi].st[H_TOPLAY]; }
+
+// scores156: NaN for illegal actions.  Returns the chosen action.
+int orc_decide(void* h, int gi, const double* w10, double* scores156, uint64_t* mask3) {
+  Game& g = ((Oracle*)h)->games[gi];
+  int n;
+  return decide(g, w10, scores156, &n, mask3);
+}
+
+// Full rollout per the SURVEY §8c contract.  Returns result (-1 draw, 0 P1, 1 P2); fills the
+// per-decision trace if given (action u8, canon hash u64 after the commit).
+int orc_rollout(void* h, int gi, const double* w_p1, const double* w_p2, int max_turns, uint8_t* trace_action,
+                uint64_t* trace_hash, int* n_steps, uint64_t* n_lookahead, int* fault_out) {
+  Game& g = ((Oracle*)h)->games[gi];
+  int steps = 0, fault = 0;
+  for (;;) {
+    Engine<FlatMem> e = engine(g);
+    if (e.have_winner() || steps >= max_turns) break;
+    const double* w = g.st[H_TOPLAY] == 0 ? w_p1 : w_p2;
+    int a = decide(g, w, nullptr, nullptr, nullptr);
+    fault = commit(g, a);
+    if (trace_action) trace_action[steps] = (uint8_t)a;
+    if (trace_hash) trace_hash[steps] = orc_canon_hash(h, gi);
+    steps++;
+    if (fault) break;  // evo/fitness.py:208-210: exception during a turn -> break -> draw
+  }
+  Engine<FlatMem> e = engine(g);
+  int result = -1;
+  if (!fault && e.have_winner()) result = game_result(e);
+  g.result = result;
+  if (n_steps) *n_steps = steps;
+  if (n_lookahead) *n_lookahead = g.lookahead_steps;
+  if (fault_out) *fault_out = fault;
+  return result;
+}
+
+// ---- RNG known-answer entry points (tests/golden/rng_kat.npz) ---------------------------------
+void orc_rng_u32(uint32_t seed, int n, uint32_t* out) {
+  Game g;
+  seed_game(g, seed);
+  for (int i = 0; i < n; i++) {
+    RngView v = view(g);
+    out[i] = v.next_u32();
+    commit_rng(g, v);
+  }
+}
+void orc_rng_random(uint32_t seed, int n, double* out) {
+  Game g;
+  seed_game(g, seed);
+  for (int i = 0; i < n; i++) {
+    RngView v = view(g);
+    out[i] = v.random_sample();
+    commit_rng(g, v);
+  }
+}
+// out[i] = randint(0, bounds[i])
+void orc_rng_randint(uint32_t seed, int n, const int* bounds, int* out) {
+  Game g;
+  seed_game(g, seed);
+  for (int i = 0; i < n; i++) {
+    RngView v = view(g);
+    out[i] = v.randint(0, bounds[i]);
+    commit_rng(g, v);
+  }
+}
+// shuffle(list(range(k))) repeated `reps` times on one stream
+void orc_rng_shuffle(uint32_t seed, int k, int reps, int* out) {
+  Game g;
+  seed_game(g, seed);
+  for (int r = 0; r < reps; r++) {
+    RngView v = view(g);
+    int* a = out + r * k;
+    for (int i = 0; i < k; i++) a[i] = i;
+    for (int i = k - 1; i >= 1; i--) {
+      int j = (int)v.interval((uint32_t)i);
+      int t = a[i];
+      a[i] = a[j];
+      a[j] = t;
+    }
+    commit_rng(g, v);
+  }
+}
+double orc_score(const double* w, const double* before, const double* after) {
+  return Engine<FlatMem>::action_score(w, before, after);
+}
+
+}  // extern "C"

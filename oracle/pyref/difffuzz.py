@@ -1,0 +1,161 @@
+#!/usr/bin/env python3
+"""Live differential check: Python reference vs the C++ restatement (liboracle.so).
+
+TEST INFRASTRUCTURE (build container only; needs /root/reference).
+For every (seed, deck pair) it plays a seeded random legal policy on the reference and mirrors
+every action on the oracle, comparing after each step: the sorted legal-action list, reward,
+done, the canonical state record byte for byte, the (27,5,4) observation and the 10 features.
+
+Usage: PYTHONHASHSEED=0 python oracle/pyref/difffuzz.py --deck N12M --games 50 [--steps 300]
+       ... --pool neutral   random 12-card decks drawn from a pool of supported cards
+"""
+import argparse
+import ctypes
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import harness as H  # noqa: E402
+
+from evo.features import StateFeatures  # noqa: E402
+
+LIB = ctypes.CDLL(os.path.join(H.REPO, "oracle", "liboracle.so"))
+LIB.orc_create.restype = ctypes.c_void_p
+LIB.orc_canon_hash.restype = ctypes.c_uint64
+for name in ("orc_reset", "orc_legal", "orc_step", "orc_observe", "orc_features", "orc_canon", "orc_destroy",
+             "orc_canon_hash", "orc_have_winner", "orc_to_play", "orc_decide"):
+    getattr(LIB, name).argtypes = None
+
+UNSUPPORTED = {"u017", "ua20", "b005", "b006", "b305", "s203"}
+FAULT_CARDS = {"up01", "up02", "up03"}
+
+
+def deck_bytes(deck):
+    return (ctypes.c_uint8 * 12)(*[H.CARD_INDEX[c] for c in deck])
+
+
+class Mirror:
+    def __init__(self):
+        self.h = ctypes.c_void_p(LIB.orc_create(1))
+
+    def reset(self, seed, d0, d1, f0=0, f1=0):
+        return LIB.orc_reset(self.h, 0, ctypes.c_uint32(seed), deck_bytes(d0), deck_bytes(d1), f0, f1)
+
+    def legal(self):
+        m = (ctypes.c_uint64 * 3)()
+        LIB.orc_legal(self.h, 0, m)
+        return [a for a in range(156) if (m[a >> 6] >> (a & 63)) & 1]
+
+    def step(self, a):
+        r, d = ctypes.c_int(), ctypes.c_int()
+        f = LIB.orc_step(self.h, 0, a, ctypes.byref(r), ctypes.byref(d))
+        return f, r.value, d.value
+
+    def canon(self):
+        buf = (ctypes.c_uint8 * 1024)()
+        n = LIB.orc_canon(self.h, 0, buf)
+        return bytes(buf[:n])
+
+    def observe(self):
+        out = np.zeros(540, dtype=np.int32)
+        r = LIB.orc_observe(self.h, 0, out.ctypes.data_as(ctypes.c_void_p))
+        return None if r else out.reshape(27, 5, 4)
+
+    def features(self):
+        f = np.zeros(10)
+        r = LIB.orc_features(self.h, 0, f.ctypes.data_as(ctypes.c_void_p))
+        return None if r else f
+
+
+def describe_diff(a, b):
+    n = min(len(a), len(b))
+    for i in range(n):
+        if a[i] != b[i]:
+            return f"first diff at byte {i}: ref={a[max(0,i-8):i+8].hex()} ours={b[max(0,i-8):i+8].hex()} (len {len(a)} vs {len(b)})"
+    return f"length {len(a)} vs {len(b)}"
+
+
+def play(seed, d0, d1, steps, policy_seed, verbose=False):
+    g = H.make_game(seed, d0, d1)
+    mir = Mirror()
+    f = mir.reset(seed, d0, d1)
+    assert f == 0, f"reset fault {f}"
+    pol = np.random.RandomState(policy_seed)
+    ca, cb = H.canon(g), mir.canon()
+    if ca != cb:
+        return f"seed {seed}: initial state differs: {describe_diff(ca, cb)}", 0
+    n = 0
+    for t in range(steps):
+        la = g.legal_actions()
+        lb = mir.legal()
+        if la != lb:
+            return f"seed {seed} step {t}: legal differs ref={la} ours={lb}", n
+        a = int(la[pol.randint(0, len(la))])
+        ref_exc = None
+        try:
+            obs, reward, done = g.step(a)
+        except Exception as e:  # noqa: BLE001
+            ref_exc = e
+        fb, rb, db = mir.step(a)
+        n += 1
+        if ref_exc is not None:
+            if fb == 0 and mir.observe() is not None:
+                return f"seed {seed} step {t} action {a}: reference raised {ref_exc!r}, ours did not", n
+            return None, n  # both faulted: the game is over for the agent layer
+        if fb != 0:
+            return f"seed {seed} step {t} action {a}: ours faulted ({fb}), reference did not", n
+        ca, cb = H.canon(g), mir.canon()
+        if ca != cb:
+            return f"seed {seed} step {t} action {a}: state differs: {describe_diff(ca, cb)}", n
+        if (reward, int(done)) != (rb, db):
+            return f"seed {seed} step {t} action {a}: reward/done ref={(reward, done)} ours={(rb, db)}", n
+        ob = mir.observe()
+        if ob is None or not np.array_equal(obs, ob):
+            bad = np.argwhere(obs != ob) if ob is not None else None
+            return f"seed {seed} step {t} action {a}: observation differs at {bad[:5].tolist() if bad is not None else 'raise'}", n
+        fa = StateFeatures(obs, g.to_play()).get_feature_vector()
+        fbv = mir.features()
+        if not np.array_equal(fa.view(np.uint64), fbv.view(np.uint64)):
+            return f"seed {seed} step {t}: features differ ref={fa} ours={fbv}", n
+        if g.have_winner():
+            break
+    return None, n
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--deck", default="N12M")
+    ap.add_argument("--deck2", default=None)
+    ap.add_argument("--pool", default=None, help="'all' = random decks from every supported card")
+    ap.add_argument("--games", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=400)
+    ap.add_argument("--seed0", type=int, default=0)
+    args = ap.parse_args()
+    total, bad = 0, 0
+    pool = None
+    if args.pool:
+        pool = [c for c in H.CARD_IDS if c not in UNSUPPORTED and c not in FAULT_CARDS]
+    for k in range(args.games):
+        seed = args.seed0 + k
+        if pool:
+            rs = np.random.RandomState(seed ^ 0x9E3779B9)
+            d0 = list(rs.choice(pool, 12, replace=False))
+            d1 = list(rs.choice(pool, 12, replace=False))
+        else:
+            d0 = H.DECKS[args.deck]
+            d1 = H.DECKS[args.deck2 or args.deck]
+        err, n = play(seed, d0, d1, args.steps, policy_seed=seed + 1000)
+        total += n
+        if err:
+            bad += 1
+            print("MISMATCH", err)
+            if pool:
+                print("   decks", d0, d1)
+    print(f"{args.games} games, {total} steps, {bad} mismatching games")
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
