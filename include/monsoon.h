@@ -1,0 +1,130 @@
+/* monsoon.h -- C ABI of the MI355X batched Stormbound engine (libmonsoon_hip.so).
+ *
+ * Drop-in boundary for ONE path of dvrp0/Monsoon: the game step / legal-action / observation
+ * surface and the heuristic self-play rollouts that score an evolutionary population.  The
+ * reference has no FFI (it is pure Python); each entry point below names the Python interface
+ * it replaces.  INTEGRATION.md shows the ctypes stubs a maintainer of the reference would add.
+ *
+ * Conventions: plain C, opaque handle, int status returns (0 = MONSOON_OK), caller-owned HOST
+ * buffers unless a name ends in _dev, no callbacks, no global state.  One handle = one HIP
+ * device + one stream; a handle is not thread-safe, independent handles are.  Per-game faults
+ * (the reference's swallowed Python exceptions) are reported as bytes, never as
+ * error returns.  There is no CPU backend: every call fails with MONSOON_ERR_DEVICE when no
+ * gfx950 device is usable.
+ */
+#ifndef MONSOON_H
+#define MONSOON_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MONSOON_OK 0
+#define MONSOON_ERR_ARG 1       /* bad argument (null pointer, size, illegal action, unsupported card) */
+#define MONSOON_ERR_DEVICE 2    /* HIP error; see monsoon_last_error */
+#define MONSOON_ERR_STATE 3     /* call order (e.g. step before reset) */
+
+#define MONSOON_NUM_ACTIONS 156 /* enums.py:10-36 */
+#define MONSOON_OBS_INTS 540    /* (27,5,4) int32, games/stormbound.py:376-399 */
+#define MONSOON_DECK_SIZE 12
+#define MONSOON_NUM_FEATURES 10 /* evo/features.py:327-342 */
+
+typedef struct monsoon monsoon_t;
+
+typedef struct {
+  int32_t device;          /* HIP device ordinal */
+  int32_t max_games;       /* capacity of the batch */
+  int32_t lanes_per_game;  /* candidate successor states resident per wavefront: 16, 32 or 64 (0 = default) */
+  int32_t stack_bytes;     /* per-lane scratch stack for the rules core's recursion (0 = default) */
+} monsoon_config;
+
+/* One scheduled game of a fitness evaluation (evo/fitness.py:53-59,133-157). */
+typedef struct {
+  int32_t p1;     /* index into the weight table: row individual, plays FIRST */
+  int32_t p2;     /* opponent, plays SECOND */
+  uint32_t seed;  /* numpy.random.RandomState(seed) of the game (games/stormbound.py:294) */
+  uint32_t deck;  /* index into the deck-pair table passed to monsoon_rollout */
+} monsoon_match;
+
+typedef struct {
+  uint64_t lookahead_steps;  /* Stormbound.step transitions executed as 1-ply look-ahead */
+  uint64_t decisions;        /* committed decisions (each commits one of its look-ahead results) */
+  uint64_t games_finished;   /* games that ended with a winner */
+  uint64_t faults;           /* games stopped by a fault (reference: swallowed exception -> draw) */
+  uint64_t capacity_faults;  /* of those, build-limit faults (must be 0 for a valid run) */
+} monsoon_stats;
+
+int monsoon_create(const monsoon_config* cfg, monsoon_t** out);
+void monsoon_destroy(monsoon_t* h);
+const char* monsoon_last_error(monsoon_t* h);   /* h may be NULL: last create() error */
+int monsoon_version(void);
+/* card id string ("u007") -> table index used in deck arrays; -1 if unknown.  card.py:15 */
+int monsoon_card_index(const char* card_id);
+/* 1 if the card's ability is implemented by this build (decks with other cards are refused) */
+int monsoon_card_supported(int card_index);
+
+/* Stormbound.__init__ for n games (games/stormbound.py:293-304, player.py:13-37):
+ * seeds[n]; decks[n][2][12] card indices in constructor order; factions[n][2] (enums.py:44-49). */
+int monsoon_reset(monsoon_t* h, int32_t n, const uint32_t* seeds, const uint8_t* decks, const uint8_t* factions);
+
+/* Stormbound.legal_actions (games/stormbound.py:528-557) as a 156-bit mask per game: out[n][3]. */
+int monsoon_legal_mask(monsoon_t* h, uint64_t* out);
+
+/* Stormbound.step (games/stormbound.py:318-373) for every game; actions[n] must be legal
+ * (actions[i] = 255 leaves game i untouched).  reward[n] in {0,1}, done[n], fault[n] (0 = none). */
+int monsoon_step(monsoon_t* h, const uint8_t* actions, int8_t* reward, uint8_t* done, uint8_t* fault);
+
+/* Stormbound.get_observation (games/stormbound.py:400-526): out[n][27][5][4] int32.
+ * raises[n] = 1 where the reference would raise (int(card) on up01/up02/up03, card.py:46). */
+int monsoon_observe(monsoon_t* h, int32_t* out, uint8_t* raises);
+
+/* StateFeatures.get_feature_vector (evo/features.py:12-342): out[n][10] float64. */
+int monsoon_features(monsoon_t* h, double* out);
+
+/* Stormbound.to_play / have_winner (games/stormbound.py:312-313, 560-561) + bases: out[n][4] =
+ * {to_play, have_winner, base_first, base_second}. */
+int monsoon_status(monsoon_t* h, int32_t* out);
+
+/* Canonical state record of game idx (layout: monsoon_amd/csrc/canon.h), the comparand of the
+ * bit-exactness tests.  buf must hold 1024 bytes. */
+int monsoon_state_export(monsoon_t* h, int32_t idx, uint8_t* buf, int32_t* len);
+
+/* HeuristicAgent.select_action + adapter.apply_action for every live game
+ * (evo/heuristic_agent.py:53-80, evo/game_adapter.py:320-325): 1-ply look-ahead over all legal
+ * actions, score, first-max argmax, commit.  weights[n][2][10]: the weight vector of the FIRST
+ * and SECOND player of each game.  out_action[n] (255 = game already over), out_score[n]
+ * (best score), out_scores[n][156] (NaN = illegal; may be NULL). */
+int monsoon_decide(monsoon_t* h, const double* weights, uint8_t* out_action, double* out_score, double* out_scores);
+
+/* FitnessEvaluator rollouts (evo/fitness.py:123-228 with the corrected loop of SURVEY.md §8c):
+ * plays n_matches games to the end (winner, fault, or max_turns decisions), at most
+ * cfg.max_games at a time.  weights[n_individuals][10]; deck_pairs[n_decks][2][12];
+ * out_counts[n_individuals][3] = {wins, draws, games} of each individual as p1, ACCUMULATED
+ * into the caller's buffer; out_results[n_matches] (may be NULL): -1 draw, 0 p1, 1 p2;
+ * out_steps[n_matches] (may be NULL): decisions played. */
+int monsoon_rollout(monsoon_t* h, const double* weights, int32_t n_individuals, const monsoon_match* matches,
+                    int32_t n_matches, const uint8_t* deck_pairs, int32_t n_decks, int32_t max_turns,
+                    int32_t* out_counts, int8_t* out_results, int32_t* out_steps);
+
+/* Device-resident variant used by bench.py: one decision round over the games already loaded by
+ * monsoon_reset, weights taken from a table uploaded once.  Nothing crosses PCIe. */
+int monsoon_upload_weights(monsoon_t* h, const double* weights, int32_t n_individuals);
+int monsoon_assign_players(monsoon_t* h, const int32_t* p1, const int32_t* p2);   /* [n] indices */
+int monsoon_decide_round_dev(monsoon_t* h);   /* asynchronous on the handle's stream */
+int monsoon_sync(monsoon_t* h);
+/* Re-seed finished games in place (keeps the batch at full occupancy for throughput runs). */
+int monsoon_respawn_finished_dev(monsoon_t* h, uint32_t seed_base);
+
+int monsoon_get_stats(monsoon_t* h, monsoon_stats* out);
+int monsoon_reset_stats(monsoon_t* h);
+/* HIP-event timing of the decide kernel since the last reset_stats: total ms and launch count. */
+int monsoon_kernel_time(monsoon_t* h, double* total_ms, int64_t* launches);
+/* Raw stream handle (hipStream_t) so a caller can order its own work; NULL-safe. */
+void* monsoon_stream(monsoon_t* h);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MONSOON_H */

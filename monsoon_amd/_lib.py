@@ -1,0 +1,89 @@
+"""ctypes binding of libmonsoon_hip.so (include/monsoon.h).
+
+The library is built in-tree by `__graft_entry__.build()` / `make -C monsoon_amd/csrc`.
+There is no fallback: if the shared object is missing or no gfx950 device is usable, every
+entry point of this package raises.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmonsoon_hip.so")
+
+OK, ERR_ARG, ERR_DEVICE, ERR_STATE = 0, 1, 2, 3
+NUM_ACTIONS = 156
+OBS_INTS = 540
+
+
+class Config(ctypes.Structure):
+    _fields_ = [("device", ctypes.c_int32), ("max_games", ctypes.c_int32), ("lanes_per_game", ctypes.c_int32),
+                ("stack_bytes", ctypes.c_int32)]
+
+
+class Match(ctypes.Structure):
+    _fields_ = [("p1", ctypes.c_int32), ("p2", ctypes.c_int32), ("seed", ctypes.c_uint32), ("deck", ctypes.c_uint32)]
+
+
+class Stats(ctypes.Structure):
+    _fields_ = [("lookahead_steps", ctypes.c_uint64), ("decisions", ctypes.c_uint64), ("games_finished", ctypes.c_uint64),
+                ("faults", ctypes.c_uint64), ("capacity_faults", ctypes.c_uint64)]
+
+
+class MonsoonError(RuntimeError):
+    pass
+
+
+_lib = None
+
+# name -> (restype, argtypes); every symbol declared in include/monsoon.h
+SIGNATURES = {
+    "monsoon_create": (ctypes.c_int, [ctypes.POINTER(Config), ctypes.POINTER(ctypes.c_void_p)]),
+    "monsoon_destroy": (None, [ctypes.c_void_p]),
+    "monsoon_last_error": (ctypes.c_char_p, [ctypes.c_void_p]),
+    "monsoon_version": (ctypes.c_int, []),
+    "monsoon_card_index": (ctypes.c_int, [ctypes.c_char_p]),
+    "monsoon_card_supported": (ctypes.c_int, [ctypes.c_int]),
+    "monsoon_reset": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
+    "monsoon_legal_mask": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p]),
+    "monsoon_step": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
+    "monsoon_observe": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
+    "monsoon_features": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p]),
+    "monsoon_status": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p]),
+    "monsoon_state_export": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p, ctypes.POINTER(ctypes.c_int32)]),
+    "monsoon_decide": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
+    "monsoon_rollout": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p, ctypes.c_int32,
+                                       ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p,
+                                       ctypes.c_void_p]),
+    "monsoon_upload_weights": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32]),
+    "monsoon_assign_players": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
+    "monsoon_decide_round_dev": (ctypes.c_int, [ctypes.c_void_p]),
+    "monsoon_sync": (ctypes.c_int, [ctypes.c_void_p]),
+    "monsoon_respawn_finished_dev": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_uint32]),
+    "monsoon_get_stats": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(Stats)]),
+    "monsoon_reset_stats": (ctypes.c_int, [ctypes.c_void_p]),
+    "monsoon_kernel_time": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int64)]),
+    "monsoon_stream": (ctypes.c_void_p, [ctypes.c_void_p]),
+}
+
+
+def load():
+    """Load the HIP library (fails loudly when it has not been built)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise MonsoonError(f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                           "or `make -C monsoon_amd/csrc` (there is no CPU fallback)")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)   # AttributeError if the ABI and this binding drift apart
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(handle, rc, what):
+    if rc != OK:
+        msg = load().monsoon_last_error(handle)
+        raise MonsoonError(f"{what} failed (status {rc}): {msg.decode() if msg else ''}")

@@ -1,0 +1,1025 @@
+// libmonsoon_hip.so -- MI355X (gfx950) batched Stormbound engine: kernels + C ABI (include/monsoon.h).
+//
+// Execution model
+//   * Hot kernel k_decide<U>: ONE WAVEFRONT PER GAME.  The game's record (960 B) is staged from
+//     HBM into LDS with one coalesced pass; the legal-action mask and the "before" features are
+//     evaluated on that shared copy (LDS broadcast reads); then up to U candidate actions are
+//     advanced at once, lane l stepping its own private copy of the state.  The private copies are
+//     word-interleaved across lanes (word w of lane l at w*U+l), so lanes touching the same field
+//     hit distinct LDS banks.  Scores are reduced with 64-lane shuffles (first maximum in
+//     ascending action order = np.argmax over the sorted legal list) and the winner's column is
+//     written back as the game's new record.  No look-ahead is re-executed when the legal set
+//     fits in U lanes (the committed successor IS one of the look-ahead results).
+//   * The game's MT19937 stream lives in HBM as two blocks of tempered outputs (current + next)
+//     plus the raw state; candidate steps read it through a private cursor, the committed
+//     cursor is stored back and the wave regenerates a block (twist in LDS) when it is used up.
+//   * API kernels (reset/step/legal/observe/features/status/export) map one LANE per game with the
+//     same LDS layout (U = 64); they back the batch=1 Game view and the parity tests.
+//   * Integer/index work: no MFMA.  f64 appears only in the weighted draw and the score.
+//
+// There is no CPU path in this library.  A missing/unsupported device is an error.
+#include <hip/hip_runtime.h>
+
+#include <math.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/monsoon.h"
+#include "canon.h"
+
+using namespace msb;
+
+namespace {
+
+constexpr int SW = (STATE_WORDS + 3) & ~3;   // record stride in HBM, words (16-byte aligned)
+constexpr int RNG_WORDS = 2 * MT_N;          // tempered outputs: two blocks per game
+
+struct GameMeta {
+  int32_t p1, p2;          // weight-table rows of the FIRST / SECOND player
+  int8_t result;           // -2 running, -1 draw, 0 FIRST won, 1 SECOND won
+  uint8_t fault;
+  uint8_t last_action;
+  uint8_t pad;
+  uint16_t steps;          // committed decisions
+  uint16_t pad2;
+  uint32_t rng;            // cursor (bits 0-15) | current block (bit 16)
+  uint32_t lookahead;      // look-ahead transitions executed for this game
+  uint32_t match;          // schedule index (rollout)
+};
+
+struct DevBuffers {
+  uint32_t* state;     // [cap][SW]
+  uint32_t* rng_out;   // [cap][2][624]
+  uint32_t* rng_mt;    // [cap][624]
+  GameMeta* meta;      // [cap]
+  double* weights;     // [n_individuals][10]
+  unsigned long long* stats;  // [8]: lookahead, decisions, finished, faults, capacity_faults
+  double* scores;      // [cap][156] or null
+  double* best;        // [cap]
+};
+
+enum { ST_LOOKAHEAD = 0, ST_DECISIONS = 1, ST_FINISHED = 2, ST_FAULTS = 3, ST_CAPFAULTS = 4 };
+
+// ------------------------------------------------------------------------------------------------
+// RNG block maintenance (wave-cooperative, in LDS)
+// ------------------------------------------------------------------------------------------------
+// In-place MT19937 twist of 624 words in LDS by one wavefront.  Within one pass all lanes read
+// before any lane writes (a wave executes in lockstep), and passes are ordered by barriers.
+__device__ void wave_twist_lds(MSB_AS_LDS uint32_t* mt, int lane) {
+  for (int k0 = 0; k0 < MT_N - MT_M; k0 += 64) {
+    int k = k0 + lane;
+    uint32_t v = 0;
+    bool on = k < MT_N - MT_M;
+    if (on) v = mt[k + MT_M] ^ mt_mix(mt[k], mt[k + 1]);
+    __syncthreads();
+    if (on) mt[k] = v;
+    __syncthreads();
+  }
+  for (int k0 = MT_N - MT_M; k0 < MT_N - 1; k0 += 64) {
+    int k = k0 + lane;
+    uint32_t v = 0;
+    bool on = k < MT_N - 1;
+    if (on) v = mt[k + (MT_M - MT_N)] ^ mt_mix(mt[k], mt[k + 1]);
+    __syncthreads();
+    if (on) mt[k] = v;
+    __syncthreads();
+  }
+  if (lane == 0) mt[MT_N - 1] = mt[MT_M - 1] ^ mt_mix(mt[MT_N - 1], mt[0]);
+  __syncthreads();
+}
+
+// Regenerate tempered block `which` of game g from the raw state (advancing it one twist).
+__device__ void wave_refill(const DevBuffers& b, int g, int which, MSB_AS_LDS uint32_t* tmp, int lane) {
+  uint32_t* mt = b.rng_mt + (size_t)g * MT_N;
+  for (int k = lane; k < MT_N; k += 64) tmp[k] = mt[k];
+  __syncthreads();
+  wave_twist_lds(tmp, lane);
+  uint32_t* out = b.rng_out + (size_t)g * RNG_WORDS + which * MT_N;
+  for (int k = lane; k < MT_N; k += 64) {
+    uint32_t v = tmp[k];
+    mt[k] = v;
+    out[k] = mt_temper(v);
+  }
+  __syncthreads();
+}
+
+__device__ MSB_INL RngView make_view(const DevBuffers& b, int g, uint32_t rng) {
+  const uint32_t* base = b.rng_out + (size_t)g * RNG_WORDS;
+  int cur = (rng >> 16) & 1;
+  return RngView{base + cur * MT_N, base + (cur ^ 1) * MT_N, rng & 0xffffu, 0};
+}
+
+// Serial form for the lane-per-game API kernels: one lane owns the game.
+__device__ void lane_commit_rng(const DevBuffers& b, int g, GameMeta& m, const RngView& v) {
+  uint32_t pos = v.pos;
+  int cur = (m.rng >> 16) & 1;
+  if (pos >= (uint32_t)MT_N) {
+    pos -= MT_N;
+    uint32_t* mt = b.rng_mt + (size_t)g * MT_N;
+    mt_twist(mt);
+    uint32_t* out = b.rng_out + (size_t)g * RNG_WORDS + cur * MT_N;
+    for (int k = 0; k < MT_N; k++) out[k] = mt_temper(mt[k]);
+    cur ^= 1;
+  }
+  m.rng = pos | ((uint32_t)cur << 16);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Lane-per-game API kernels.  Block = 64 threads, state staged in LDS word-interleaved.
+// ------------------------------------------------------------------------------------------------
+struct ApiLds {
+  uint32_t w[SW * 64];
+};
+
+__device__ MSB_INL void api_load(MSB_AS_LDS uint32_t* col, const uint32_t* src) {
+  for (int w = 0; w < STATE_WORDS; w++) col[w * 64] = src[w];
+}
+__device__ MSB_INL void api_store(uint32_t* dst, MSB_AS_LDS const uint32_t* col) {
+  for (int w = 0; w < STATE_WORDS; w++) dst[w] = col[w * 64];
+}
+
+__global__ void __launch_bounds__(64) k_seed(DevBuffers b, int n, const uint32_t* seeds) {
+  // one wavefront per game: init_genrand is a serial recurrence (lane 0), the two twists are
+  // wave-cooperative
+  __shared__ uint32_t tmp[MT_N];
+  int g = blockIdx.x, lane = threadIdx.x;
+  if (g >= n) return;
+  MSB_AS_LDS uint32_t* t = (MSB_AS_LDS uint32_t*)tmp;
+  if (lane == 0) {
+    uint32_t x = seeds[g];
+    t[0] = x;
+    for (int i = 1; i < MT_N; i++) {
+      x = 1812433253u * (x ^ (x >> 30)) + (uint32_t)i;
+      t[i] = x;
+    }
+  }
+  __syncthreads();
+  uint32_t* mt = b.rng_mt + (size_t)g * MT_N;
+  for (int k = lane; k < MT_N; k += 64) mt[k] = t[k];
+  __syncthreads();
+  wave_refill(b, g, 0, t, lane);
+  wave_refill(b, g, 1, t, lane);
+}
+
+__global__ void __launch_bounds__(64) k_init(DevBuffers b, int n, const uint8_t* decks, const uint8_t* factions) {
+  __shared__ ApiLds lds;
+  int g = blockIdx.x * 64 + threadIdx.x;
+  if (g >= n) return;
+  Engine<LdsMem> e;
+  e.m.base = (MSB_AS_LDS uint32_t*)lds.w + threadIdx.x;
+  e.m.stride = 64;
+  GameMeta m = b.meta[g];
+  m.rng = 0;
+  e.rng = make_view(b, g, m.rng);
+  uint8_t d0[12], d1[12];
+  for (int i = 0; i < 12; i++) {
+    d0[i] = decks[(size_t)g * 24 + i];
+    d1[i] = decks[(size_t)g * 24 + 12 + i];
+  }
+  e.init_game(d0, d1, factions[2 * g], factions[2 * g + 1]);
+  lane_commit_rng(b, g, m, e.rng);
+  m.result = -2;
+  m.fault = (uint8_t)e.fault();
+  m.last_action = 255;
+  m.steps = 0;
+  m.lookahead = 0;
+  b.meta[g] = m;
+  api_store(b.state + (size_t)g * SW, e.m.base);
+}
+
+__global__ void __launch_bounds__(64) k_legal(DevBuffers b, int n, uint64_t* out) {
+  __shared__ ApiLds lds;
+  int g = blockIdx.x * 64 + threadIdx.x;
+  if (g >= n) return;
+  Engine<LdsMem> e;
+  e.m.base = (MSB_AS_LDS uint32_t*)lds.w + threadIdx.x;
+  e.m.stride = 64;
+  api_load(e.m.base, b.state + (size_t)g * SW);
+  uint64_t mask[3];
+  e.legal_mask(mask);
+  out[3 * g] = mask[0];
+  out[3 * g + 1] = mask[1];
+  out[3 * g + 2] = mask[2];
+}
+
+__global__ void __launch_bounds__(64) k_step(DevBuffers b, int n, const uint8_t* actions, int8_t* reward, uint8_t* done,
+                                              uint8_t* fault, uint8_t* illegal) {
+  __shared__ ApiLds lds;
+  int g = blockIdx.x * 64 + threadIdx.x;
+  if (g >= n) return;
+  int a = actions[g];
+  reward[g] = 0;
+  done[g] = 0;
+  fault[g] = 0;
+  illegal[g] = 0;
+  if (a == 255) return;
+  Engine<LdsMem> e;
+  e.m.base = (MSB_AS_LDS uint32_t*)lds.w + threadIdx.x;
+  e.m.stride = 64;
+  api_load(e.m.base, b.state + (size_t)g * SW);
+  uint64_t mask[3];
+  e.legal_mask(mask);
+  if (a >= 156 || !((mask[a >> 6] >> (a & 63)) & 1)) {
+    illegal[g] = 1;
+    return;
+  }
+  GameMeta m = b.meta[g];
+  e.rng = make_view(b, g, m.rng);
+  int r = 0, d = 0;
+  e.step(a, &r, &d);
+  reward[g] = (int8_t)r;
+  done[g] = (uint8_t)d;
+  fault[g] = (uint8_t)e.fault();
+  lane_commit_rng(b, g, m, e.rng);
+  m.steps++;
+  m.last_action = (uint8_t)a;
+  if (e.fault()) m.fault = (uint8_t)e.fault();
+  b.meta[g] = m;
+  api_store(b.state + (size_t)g * SW, e.m.base);
+}
+
+__global__ void __launch_bounds__(64) k_observe(DevBuffers b, int n, int32_t* out, uint8_t* raises) {
+  __shared__ ApiLds lds;
+  int g = blockIdx.x * 64 + threadIdx.x;
+  if (g >= n) return;
+  Engine<LdsMem> e;
+  e.m.base = (MSB_AS_LDS uint32_t*)lds.w + threadIdx.x;
+  e.m.stride = 64;
+  api_load(e.m.base, b.state + (size_t)g * SW);
+  bool r = e.observation_raises();
+  raises[g] = r ? 1 : 0;
+  if (!r) e.observe(out + (size_t)g * MONSOON_OBS_INTS);
+}
+
+__global__ void __launch_bounds__(64) k_features(DevBuffers b, int n, double* out) {
+  __shared__ ApiLds lds;
+  int g = blockIdx.x * 64 + threadIdx.x;
+  if (g >= n) return;
+  Engine<LdsMem> e;
+  e.m.base = (MSB_AS_LDS uint32_t*)lds.w + threadIdx.x;
+  e.m.stride = 64;
+  api_load(e.m.base, b.state + (size_t)g * SW);
+  double f[10];
+  if (e.observation_raises()) {
+    for (int i = 0; i < 10; i++) f[i] = NAN;
+  } else {
+    e.features(f);
+  }
+  for (int i = 0; i < 10; i++) out[(size_t)g * 10 + i] = f[i];
+}
+
+__global__ void __launch_bounds__(64) k_status(DevBuffers b, int n, int32_t* out) {
+  int g = blockIdx.x * 64 + threadIdx.x;
+  if (g >= n) return;
+  FlatMem fm{(uint8_t*)(b.state + (size_t)g * SW)};
+  Engine<FlatMem> e;
+  e.m = fm;
+  out[4 * g] = e.local();
+  out[4 * g + 1] = e.have_winner() ? 1 : 0;
+  out[4 * g + 2] = e.pl_base(0);
+  out[4 * g + 3] = e.pl_base(1);
+}
+
+__global__ void __launch_bounds__(64) k_export(DevBuffers b, int g, uint8_t* out, int32_t* len) {
+  __shared__ ApiLds lds;
+  if (threadIdx.x != 0) return;
+  Engine<LdsMem> e;
+  e.m.base = (MSB_AS_LDS uint32_t*)lds.w;
+  e.m.stride = 64;
+  api_load(e.m.base, b.state + (size_t)g * SW);
+  RngView v = make_view(b, g, b.meta[g].rng);
+  uint32_t nx = v.next_u32();
+  *len = canon_record(e, nx, out);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Hot kernel: one decision (look-ahead + score + argmax + commit) per game, one wavefront per game.
+// ------------------------------------------------------------------------------------------------
+__device__ MSB_INL int nth_set_bit(const uint64_t mask[3], int k) {
+  for (int w = 0; w < 3; w++) {
+    int c = __popcll(mask[w]);
+    if (k < c) {
+      uint64_t m = mask[w];
+      for (int i = 0; i < k; i++) m &= m - 1;
+      return w * 64 + __ffsll((long long)m) - 1;
+    }
+    k -= c;
+  }
+  return -1;
+}
+
+template <int U>
+__global__ void __launch_bounds__(64) k_decide(DevBuffers b, int n, int max_turns, int write_scores) {
+  constexpr int PRIV_WORDS = SW * U;
+  static_assert(PRIV_WORDS >= MT_N, "private region doubles as the twist buffer");
+  __shared__ uint32_t s_par[SW];
+  __shared__ uint32_t s_priv[PRIV_WORDS];
+  const int g = blockIdx.x;
+  const int lane = threadIdx.x;
+  if (g >= n) return;
+  GameMeta meta = b.meta[g];
+  if (meta.result != -2) {
+    if (lane == 0) {
+      b.meta[g].last_action = 255;
+      if (b.best) b.best[g] = NAN;
+    }
+    return;
+  }
+  MSB_AS_LDS uint32_t* par = (MSB_AS_LDS uint32_t*)s_par;
+  MSB_AS_LDS uint32_t* priv = (MSB_AS_LDS uint32_t*)s_priv;
+  uint32_t* grec = b.state + (size_t)g * SW;
+  for (int w = lane; w < SW; w += 64) par[w] = grec[w];
+  __syncthreads();
+
+  Engine<LdsMem> pe;
+  pe.m.base = par;
+  pe.m.stride = 1;
+  pe.rng = make_view(b, g, meta.rng);
+
+  // rollout contract: while not have_winner() and steps < max_turns
+  if (pe.have_winner() || meta.steps >= max_turns) {
+    if (lane == 0) {
+      int b0 = pe.pl_base(0), b1 = pe.pl_base(1);
+      int res = -1;
+      if (pe.have_winner()) res = (b1 < 0 && b0 >= 0) ? 0 : (b0 < 0 && b1 >= 0) ? 1 : -1;
+      meta.result = (int8_t)res;
+      meta.last_action = 255;
+      b.meta[g] = meta;
+      if (pe.have_winner()) atomicAdd(&b.stats[ST_FINISHED], 1ull);
+      if (b.best) b.best[g] = NAN;
+    }
+    return;
+  }
+
+  uint64_t mask[3];
+  pe.legal_mask(mask);
+  const int n_legal = __popcll(mask[0]) + __popcll(mask[1]) + __popcll(mask[2]);
+  const bool before_raises = pe.observation_raises();
+  double fb[10];
+  if (!before_raises) pe.features(fb);
+  const double* wt = b.weights + (size_t)(pe.local() == 0 ? meta.p1 : meta.p2) * 10;
+  double w[10];
+  for (int i = 0; i < 10; i++) w[i] = wt[i];
+
+  Engine<LdsMem> ce;
+  ce.m.base = priv + lane;
+  ce.m.stride = U;
+  double best_s = 0.0;
+  int best_a = 1 << 20;
+  uint32_t my_pos = 0;
+  int my_fault = 0;
+  for (int base = 0; base < n_legal; base += U) {
+    int k = base + lane;
+    if (lane < U && k < n_legal) {
+      int a = nth_set_bit(mask, k);
+      for (int i = 0; i < STATE_WORDS; i++) priv[i * U + lane] = par[i];
+      ce.rng = pe.rng;
+      int r, d;
+      ce.step(a, &r, &d);
+      double s = 0.0;   // except Exception -> 0.0 (evo/heuristic_agent.py:48-51)
+      int f = ce.fault();
+      bool raises = f == 0 && ce.observation_raises();
+      if (f == 0 && !before_raises && !raises) {
+        double fa[10];
+        ce.features(fa);
+        s = Engine<LdsMem>::action_score(w, fb, fa);
+      }
+      if (write_scores) b.scores[(size_t)g * MONSOON_NUM_ACTIONS + a] = s;
+      if (best_a == (1 << 20) || s > best_s) {
+        best_s = s;
+        best_a = a;
+        my_pos = ce.rng.pos;
+        my_fault = f ? f : (raises ? FAULT_INT_CARD : 0);
+      }
+    }
+  }
+  // first maximum over the ascending legal list == (max score, then min action id)
+  double rs = best_s;
+  int ra = best_a;
+  for (int off = 32; off >= 1; off >>= 1) {
+    double os = __shfl_xor(rs, off);
+    int oa = __shfl_xor(ra, off);
+    bool take = (oa != (1 << 20)) && (ra == (1 << 20) || os > rs || (os == rs && oa < ra));
+    if (take) {
+      rs = os;
+      ra = oa;
+    }
+  }
+  const int A = ra;
+  int wl;   // lane whose column holds the committed successor
+  uint32_t new_pos;
+  int cfault;
+  if (n_legal <= U) {
+    unsigned long long bal = __ballot(best_a == A);
+    wl = __ffsll((long long)bal) - 1;
+    new_pos = __shfl(my_pos, wl);
+    cfault = __shfl(my_fault, wl);
+  } else {
+    // the legal set did not fit in one pass: replay the chosen action once on lane 0
+    wl = 0;
+    if (lane == 0) {
+      for (int i = 0; i < STATE_WORDS; i++) priv[i * U] = par[i];
+      ce.rng = pe.rng;
+      int r, d;
+      ce.step(A, &r, &d);
+      my_pos = ce.rng.pos;
+      my_fault = ce.fault() ? ce.fault() : (ce.observation_raises() ? FAULT_INT_CARD : 0);
+    }
+    new_pos = __shfl(my_pos, 0);
+    cfault = __shfl(my_fault, 0);
+  }
+  __syncthreads();
+  // commit: adapter = adapter.apply_action(best)
+  for (int i = lane; i < STATE_WORDS; i += 64) grec[i] = priv[i * U + wl];
+  __syncthreads();
+  int cur = (meta.rng >> 16) & 1;
+  if (new_pos >= (uint32_t)MT_N) {
+    new_pos -= MT_N;
+    wave_refill(b, g, cur, priv, lane);   // the used-up block becomes the new "next" block
+    cur ^= 1;
+  }
+  if (lane == 0) {
+    meta.rng = new_pos | ((uint32_t)cur << 16);
+    meta.steps++;
+    meta.last_action = (uint8_t)A;
+    int executed = n_legal + (n_legal > U ? 1 : 0);
+    meta.lookahead += (uint32_t)executed;
+    atomicAdd(&b.stats[ST_LOOKAHEAD], (unsigned long long)executed);
+    atomicAdd(&b.stats[ST_DECISIONS], 1ull);
+    if (cfault) {
+      // evo/fitness.py:208-210: an exception while applying the action ends the game as a draw
+      meta.fault = (uint8_t)cfault;
+      meta.result = -1;
+      atomicAdd(&b.stats[ST_FAULTS], 1ull);
+      if (cfault >= FAULT_CAPACITY) atomicAdd(&b.stats[ST_CAPFAULTS], 1ull);
+    }
+    b.meta[g] = meta;
+    if (b.best) b.best[g] = rs;
+  }
+}
+
+__global__ void k_clear_scores(double* scores, size_t n) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) scores[i] = NAN;
+}
+
+__global__ void k_assign(DevBuffers b, int n, const int32_t* p1, const int32_t* p2) {
+  int g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= n) return;
+  b.meta[g].p1 = p1[g];
+  b.meta[g].p2 = p2[g];
+}
+
+// Count live games (rollout loop exit test) and collect per-individual tallies.
+__global__ void k_count_live(DevBuffers b, int n, int* live) {
+  int g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= n) return;
+  if (b.meta[g].result == -2) atomicAdd(live, 1);
+}
+
+__global__ void k_collect(DevBuffers b, int n, int32_t* counts, int8_t* results, int32_t* steps) {
+  int g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= n) return;
+  GameMeta m = b.meta[g];
+  int r = m.result == -2 ? -1 : m.result;
+  // evo/fitness.py:160-166: wins + 0.5*draws for the row individual (p1)
+  if (r == 0) atomicAdd(&counts[3 * m.p1 + 0], 1);
+  if (r == -1) atomicAdd(&counts[3 * m.p1 + 1], 1);
+  atomicAdd(&counts[3 * m.p1 + 2], 1);
+  if (results) results[m.match] = (int8_t)r;
+  if (steps) steps[m.match] = m.steps;
+}
+
+__global__ void k_set_match(DevBuffers b, int n, int base) {
+  int g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= n) return;
+  b.meta[g].match = base + g;
+}
+
+}  // namespace
+
+// ================================================================================================
+// Host side
+// ================================================================================================
+struct monsoon {
+  monsoon_config cfg;
+  int device;
+  hipStream_t stream;
+  DevBuffers b;
+  int n;              // games loaded by the last reset
+  int n_individuals;
+  std::string err;
+  // scratch device buffers for API calls
+  uint8_t* d_bytes;   // cap * max(24, 1024/…)
+  uint8_t* d_decks;   // [cap][24]
+  uint8_t* d_factions;
+  uint32_t* d_seeds;
+  uint64_t* d_masks;
+  int32_t* d_i32;     // cap * 540
+  double* d_f64;      // cap * 10
+  int32_t* d_p1;
+  int32_t* d_p2;
+  int* d_int;
+  hipEvent_t ev0, ev1;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;   // decide-kernel timing pairs
+  double kernel_ms;
+  long long kernel_launches;
+};
+
+static std::string g_create_error;
+
+#define HIP_TRY(h, call)                                                                  \
+  do {                                                                                    \
+    hipError_t e_ = (call);                                                               \
+    if (e_ != hipSuccess) {                                                               \
+      (h)->err = std::string(#call) + ": " + hipGetErrorString(e_);                      \
+      return MONSOON_ERR_DEVICE;                                                          \
+    }                                                                                     \
+  } while (0)
+
+static const char* kCardIds[NUM_CARDS] = {
+#define X(id) #id,
+#include "card_id_strings.inc"
+#undef X
+};
+
+// Cards whose abilities this build does not restate yet (abilities.inc header).
+static bool card_unsupported(int c) {
+  return c == C_U017 || c == C_UA20 || c == C_B005 || c == C_B006 || c == C_B305 || c == C_S203;
+}
+
+extern "C" {
+
+int monsoon_version(void) { return 1; }
+
+int monsoon_card_index(const char* id) {
+  if (!id) return -1;
+  for (int i = 0; i < NUM_CARDS; i++)
+    if (strcmp(kCardIds[i], id) == 0) return i;
+  return -1;
+}
+int monsoon_card_supported(int c) { return c >= 0 && c < NUM_CARDS && !card_unsupported(c); }
+
+const char* monsoon_last_error(monsoon_t* h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+
+void monsoon_destroy(monsoon_t* h) {
+  if (!h) return;
+  hipSetDevice(h->device);
+  void* ptrs[] = {h->b.state, h->b.rng_out, h->b.rng_mt, h->b.meta, h->b.weights, h->b.stats, h->b.scores, h->b.best,
+                  h->d_bytes, h->d_decks, h->d_factions, h->d_seeds, h->d_masks, h->d_i32, h->d_f64, h->d_p1, h->d_p2, h->d_int};
+  for (void* p : ptrs)
+    if (p) hipFree(p);
+  for (auto& pr : h->pending) {
+    hipEventDestroy(pr.first);
+    hipEventDestroy(pr.second);
+  }
+  if (h->stream) hipStreamDestroy(h->stream);
+  delete h;
+}
+
+int monsoon_create(const monsoon_config* cfg, monsoon_t** out) {
+  if (!cfg || !out || cfg->max_games <= 0) {
+    g_create_error = "monsoon_create: bad config";
+    return MONSOON_ERR_ARG;
+  }
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0 || cfg->device >= ndev) {
+    g_create_error = "monsoon_create: no usable HIP device (this library has no CPU path)";
+    return MONSOON_ERR_DEVICE;
+  }
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, cfg->device) != hipSuccess) {
+    g_create_error = "monsoon_create: hipGetDeviceProperties failed";
+    return MONSOON_ERR_DEVICE;
+  }
+  if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+    g_create_error = std::string("monsoon_create: built for gfx950, device is ") + prop.gcnArchName;
+    return MONSOON_ERR_DEVICE;
+  }
+  monsoon* h = new monsoon();
+  memset(&h->b, 0, sizeof(h->b));
+  h->cfg = *cfg;
+  if (h->cfg.lanes_per_game != 16 && h->cfg.lanes_per_game != 32 && h->cfg.lanes_per_game != 64) h->cfg.lanes_per_game = 32;
+  if (h->cfg.stack_bytes <= 0) h->cfg.stack_bytes = 16384;
+  h->device = cfg->device;
+  h->n = 0;
+  h->n_individuals = 0;
+  h->stream = nullptr;
+  h->d_bytes = nullptr; h->d_decks = nullptr; h->d_factions = nullptr; h->d_seeds = nullptr; h->d_masks = nullptr;
+  h->d_i32 = nullptr; h->d_f64 = nullptr; h->d_p1 = nullptr; h->d_p2 = nullptr; h->d_int = nullptr;
+  h->kernel_ms = 0;
+  h->kernel_launches = 0;
+  *out = h;
+  size_t cap = (size_t)cfg->max_games;
+  HIP_TRY(h, hipSetDevice(h->device));
+  // the rules core recurses (move -> ability -> ...): give every lane a scratch stack
+  HIP_TRY(h, hipDeviceSetLimit(hipLimitStackSize, (size_t)h->cfg.stack_bytes));
+  HIP_TRY(h, hipStreamCreate(&h->stream));
+  HIP_TRY(h, hipMalloc(&h->b.state, cap * SW * 4));
+  HIP_TRY(h, hipMalloc(&h->b.rng_out, cap * RNG_WORDS * 4));
+  HIP_TRY(h, hipMalloc(&h->b.rng_mt, cap * MT_N * 4));
+  HIP_TRY(h, hipMalloc(&h->b.meta, cap * sizeof(GameMeta)));
+  HIP_TRY(h, hipMemset(h->b.meta, 0, cap * sizeof(GameMeta)));
+  HIP_TRY(h, hipMalloc(&h->b.stats, 8 * sizeof(unsigned long long)));
+  HIP_TRY(h, hipMemset(h->b.stats, 0, 8 * sizeof(unsigned long long)));
+  HIP_TRY(h, hipMalloc(&h->b.best, cap * sizeof(double)));
+  HIP_TRY(h, hipMalloc(&h->d_decks, cap * 24));
+  HIP_TRY(h, hipMalloc(&h->d_factions, cap * 2));
+  HIP_TRY(h, hipMalloc(&h->d_seeds, cap * 4));
+  HIP_TRY(h, hipMalloc(&h->d_masks, cap * 24));
+  HIP_TRY(h, hipMalloc(&h->d_bytes, cap * 8 > 4096 ? cap * 8 : 4096));
+  HIP_TRY(h, hipMalloc(&h->d_p1, cap * 4));
+  HIP_TRY(h, hipMalloc(&h->d_p2, cap * 4));
+  HIP_TRY(h, hipMalloc(&h->d_int, 64));
+  return MONSOON_OK;
+}
+
+static int check_ready(monsoon_t* h) {
+  if (!h) return MONSOON_ERR_ARG;
+  if (h->n <= 0) {
+    h->err = "no games loaded: call monsoon_reset first";
+    return MONSOON_ERR_STATE;
+  }
+  hipError_t e = hipSetDevice(h->device);
+  if (e != hipSuccess) {
+    h->err = std::string("hipSetDevice: ") + hipGetErrorString(e);
+    return MONSOON_ERR_DEVICE;
+  }
+  return MONSOON_OK;
+}
+
+static int launch_reset(monsoon_t* h, int n) {
+  hipLaunchKernelGGL(k_seed, dim3(n), dim3(64), 0, h->stream, h->b, n, h->d_seeds);
+  hipLaunchKernelGGL(k_init, dim3((n + 63) / 64), dim3(64), 0, h->stream, h->b, n, h->d_decks, h->d_factions);
+  HIP_TRY(h, hipGetLastError());
+  return MONSOON_OK;
+}
+
+int monsoon_reset(monsoon_t* h, int32_t n, const uint32_t* seeds, const uint8_t* decks, const uint8_t* factions) {
+  if (!h || !seeds || !decks || n <= 0 || n > h->cfg.max_games) {
+    if (h) h->err = "monsoon_reset: bad argument";
+    return MONSOON_ERR_ARG;
+  }
+  for (size_t i = 0; i < (size_t)n * 24; i++) {
+    if (decks[i] >= NUM_CARDS || card_unsupported(decks[i])) {
+      h->err = std::string("monsoon_reset: card not supported by this build: ") +
+               (decks[i] < NUM_CARDS ? kCardIds[decks[i]] : "index out of range");
+      return MONSOON_ERR_ARG;
+    }
+  }
+  HIP_TRY(h, hipSetDevice(h->device));
+  HIP_TRY(h, hipMemcpyAsync(h->d_seeds, seeds, (size_t)n * 4, hipMemcpyHostToDevice, h->stream));
+  HIP_TRY(h, hipMemcpyAsync(h->d_decks, decks, (size_t)n * 24, hipMemcpyHostToDevice, h->stream));
+  if (factions)
+    HIP_TRY(h, hipMemcpyAsync(h->d_factions, factions, (size_t)n * 2, hipMemcpyHostToDevice, h->stream));
+  else
+    HIP_TRY(h, hipMemsetAsync(h->d_factions, 0, (size_t)n * 2, h->stream));
+  HIP_TRY(h, hipMemsetAsync(h->b.meta, 0, (size_t)n * sizeof(GameMeta), h->stream));
+  int rc = launch_reset(h, n);
+  if (rc) return rc;
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  h->n = n;
+  return MONSOON_OK;
+}
+
+int monsoon_legal_mask(monsoon_t* h, uint64_t* out) {
+  int rc = check_ready(h);
+  if (rc) return rc;
+  if (!out) return MONSOON_ERR_ARG;
+  int n = h->n;
+  hipLaunchKernelGGL(k_legal, dim3((n + 63) / 64), dim3(64), 0, h->stream, h->b, n, h->d_masks);
+  HIP_TRY(h, hipGetLastError());
+  HIP_TRY(h, hipMemcpyAsync(out, h->d_masks, (size_t)n * 24, hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  return MONSOON_OK;
+}
+
+int monsoon_step(monsoon_t* h, const uint8_t* actions, int8_t* reward, uint8_t* done, uint8_t* fault) {
+  int rc = check_ready(h);
+  if (rc) return rc;
+  if (!actions) return MONSOON_ERR_ARG;
+  int n = h->n;
+  uint8_t* d = h->d_bytes;   // [actions | reward | done | fault | illegal] x n
+  HIP_TRY(h, hipMemcpyAsync(d, actions, n, hipMemcpyHostToDevice, h->stream));
+  hipLaunchKernelGGL(k_step, dim3((n + 63) / 64), dim3(64), 0, h->stream, h->b, n, d, (int8_t*)(d + n), d + 2 * (size_t)n,
+                     d + 3 * (size_t)n, d + 4 * (size_t)n);
+  HIP_TRY(h, hipGetLastError());
+  std::vector<uint8_t> host(4 * (size_t)n);
+  HIP_TRY(h, hipMemcpyAsync(host.data(), d + n, 4 * (size_t)n, hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  for (int i = 0; i < n; i++) {
+    if (host[3 * (size_t)n + i]) {
+      h->err = "monsoon_step: illegal action " + std::to_string(actions[i]) + " for game " + std::to_string(i);
+      return MONSOON_ERR_ARG;
+    }
+  }
+  if (reward) memcpy(reward, host.data(), n);
+  if (done) memcpy(done, host.data() + n, n);
+  if (fault) memcpy(fault, host.data() + 2 * (size_t)n, n);
+  return MONSOON_OK;
+}
+
+int monsoon_observe(monsoon_t* h, int32_t* out, uint8_t* raises) {
+  int rc = check_ready(h);
+  if (rc) return rc;
+  if (!out) return MONSOON_ERR_ARG;
+  int n = h->n;
+  if (!h->d_i32) HIP_TRY(h, hipMalloc(&h->d_i32, (size_t)h->cfg.max_games * MONSOON_OBS_INTS * 4));
+  hipLaunchKernelGGL(k_observe, dim3((n + 63) / 64), dim3(64), 0, h->stream, h->b, n, h->d_i32, h->d_bytes);
+  HIP_TRY(h, hipGetLastError());
+  HIP_TRY(h, hipMemcpyAsync(out, h->d_i32, (size_t)n * MONSOON_OBS_INTS * 4, hipMemcpyDeviceToHost, h->stream));
+  std::vector<uint8_t> r(n);
+  HIP_TRY(h, hipMemcpyAsync(r.data(), h->d_bytes, n, hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  if (raises) memcpy(raises, r.data(), n);
+  return MONSOON_OK;
+}
+
+int monsoon_features(monsoon_t* h, double* out) {
+  int rc = check_ready(h);
+  if (rc) return rc;
+  if (!out) return MONSOON_ERR_ARG;
+  int n = h->n;
+  if (!h->d_f64) HIP_TRY(h, hipMalloc(&h->d_f64, (size_t)h->cfg.max_games * 10 * 8));
+  hipLaunchKernelGGL(k_features, dim3((n + 63) / 64), dim3(64), 0, h->stream, h->b, n, h->d_f64);
+  HIP_TRY(h, hipGetLastError());
+  HIP_TRY(h, hipMemcpyAsync(out, h->d_f64, (size_t)n * 80, hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  return MONSOON_OK;
+}
+
+int monsoon_status(monsoon_t* h, int32_t* out) {
+  int rc = check_ready(h);
+  if (rc) return rc;
+  if (!out) return MONSOON_ERR_ARG;
+  int n = h->n;
+  if (!h->d_i32) HIP_TRY(h, hipMalloc(&h->d_i32, (size_t)h->cfg.max_games * MONSOON_OBS_INTS * 4));
+  hipLaunchKernelGGL(k_status, dim3((n + 63) / 64), dim3(64), 0, h->stream, h->b, n, h->d_i32);
+  HIP_TRY(h, hipGetLastError());
+  HIP_TRY(h, hipMemcpyAsync(out, h->d_i32, (size_t)n * 16, hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  return MONSOON_OK;
+}
+
+int monsoon_state_export(monsoon_t* h, int32_t idx, uint8_t* buf, int32_t* len) {
+  int rc = check_ready(h);
+  if (rc) return rc;
+  if (!buf || !len || idx < 0 || idx >= h->n) return MONSOON_ERR_ARG;
+  hipLaunchKernelGGL(k_export, dim3(1), dim3(64), 0, h->stream, h->b, idx, h->d_bytes, (int32_t*)(h->d_bytes + 2048));
+  HIP_TRY(h, hipGetLastError());
+  uint8_t host[2048 + 4];
+  HIP_TRY(h, hipMemcpyAsync(host, h->d_bytes, sizeof(host), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  int32_t n;
+  memcpy(&n, host + 2048, 4);
+  memcpy(buf, host, n);
+  *len = n;
+  return MONSOON_OK;
+}
+
+int monsoon_upload_weights(monsoon_t* h, const double* weights, int32_t n_individuals) {
+  if (!h || !weights || n_individuals <= 0) return MONSOON_ERR_ARG;
+  HIP_TRY(h, hipSetDevice(h->device));
+  if (n_individuals > h->n_individuals) {
+    if (h->b.weights) HIP_TRY(h, hipFree(h->b.weights));
+    h->b.weights = nullptr;
+    HIP_TRY(h, hipMalloc(&h->b.weights, (size_t)n_individuals * 80));
+    h->n_individuals = n_individuals;
+  }
+  HIP_TRY(h, hipMemcpyAsync(h->b.weights, weights, (size_t)n_individuals * 80, hipMemcpyHostToDevice, h->stream));
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  return MONSOON_OK;
+}
+
+int monsoon_assign_players(monsoon_t* h, const int32_t* p1, const int32_t* p2) {
+  int rc = check_ready(h);
+  if (rc) return rc;
+  if (!p1 || !p2) return MONSOON_ERR_ARG;
+  int n = h->n;
+  for (int i = 0; i < n; i++)
+    if (p1[i] < 0 || p2[i] < 0 || p1[i] >= h->n_individuals || p2[i] >= h->n_individuals) {
+      h->err = "monsoon_assign_players: index outside the uploaded weight table";
+      return MONSOON_ERR_ARG;
+    }
+  HIP_TRY(h, hipMemcpyAsync(h->d_p1, p1, (size_t)n * 4, hipMemcpyHostToDevice, h->stream));
+  HIP_TRY(h, hipMemcpyAsync(h->d_p2, p2, (size_t)n * 4, hipMemcpyHostToDevice, h->stream));
+  hipLaunchKernelGGL(k_assign, dim3((n + 255) / 256), dim3(256), 0, h->stream, h->b, n, h->d_p1, h->d_p2);
+  HIP_TRY(h, hipGetLastError());
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  return MONSOON_OK;
+}
+
+static int launch_decide(monsoon_t* h, int n, int max_turns, int write_scores, bool timed) {
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  if (timed) {
+    HIP_TRY(h, hipEventCreate(&e0));
+    HIP_TRY(h, hipEventCreate(&e1));
+    HIP_TRY(h, hipEventRecord(e0, h->stream));
+  }
+  switch (h->cfg.lanes_per_game) {
+    case 16: hipLaunchKernelGGL(k_decide<16>, dim3(n), dim3(64), 0, h->stream, h->b, n, max_turns, write_scores); break;
+    case 64: hipLaunchKernelGGL(k_decide<64>, dim3(n), dim3(64), 0, h->stream, h->b, n, max_turns, write_scores); break;
+    default: hipLaunchKernelGGL(k_decide<32>, dim3(n), dim3(64), 0, h->stream, h->b, n, max_turns, write_scores); break;
+  }
+  HIP_TRY(h, hipGetLastError());
+  if (timed) {
+    HIP_TRY(h, hipEventRecord(e1, h->stream));
+    h->pending.emplace_back(e0, e1);
+  }
+  return MONSOON_OK;
+}
+
+static int drain_timing(monsoon_t* h) {
+  for (auto& pr : h->pending) {
+    HIP_TRY(h, hipEventSynchronize(pr.second));
+    float ms = 0;
+    HIP_TRY(h, hipEventElapsedTime(&ms, pr.first, pr.second));
+    h->kernel_ms += ms;
+    h->kernel_launches++;
+    hipEventDestroy(pr.first);
+    hipEventDestroy(pr.second);
+  }
+  h->pending.clear();
+  return MONSOON_OK;
+}
+
+int monsoon_decide_round_dev(monsoon_t* h) {
+  int rc = check_ready(h);
+  if (rc) return rc;
+  if (!h->b.weights) {
+    h->err = "monsoon_decide_round_dev: upload weights and assign players first";
+    return MONSOON_ERR_STATE;
+  }
+  return launch_decide(h, h->n, 0x7fff, 0, true);
+}
+
+int monsoon_sync(monsoon_t* h) {
+  if (!h) return MONSOON_ERR_ARG;
+  HIP_TRY(h, hipSetDevice(h->device));
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  return drain_timing(h);
+}
+
+int monsoon_decide(monsoon_t* h, const double* weights, uint8_t* out_action, double* out_score, double* out_scores) {
+  int rc = check_ready(h);
+  if (rc) return rc;
+  if (!weights) return MONSOON_ERR_ARG;
+  int n = h->n;
+  // weights[n][2][10] -> table of 2n rows, game g plays rows 2g / 2g+1
+  rc = monsoon_upload_weights(h, weights, 2 * n);
+  if (rc) return rc;
+  std::vector<int32_t> p1(n), p2(n);
+  for (int i = 0; i < n; i++) {
+    p1[i] = 2 * i;
+    p2[i] = 2 * i + 1;
+  }
+  rc = monsoon_assign_players(h, p1.data(), p2.data());
+  if (rc) return rc;
+  if (out_scores) {
+    if (!h->b.scores) HIP_TRY(h, hipMalloc(&h->b.scores, (size_t)h->cfg.max_games * MONSOON_NUM_ACTIONS * 8));
+    size_t cnt = (size_t)n * MONSOON_NUM_ACTIONS;
+    hipLaunchKernelGGL(k_clear_scores, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, h->stream, h->b.scores, cnt);
+  }
+  rc = launch_decide(h, n, 0x7fff, out_scores ? 1 : 0, false);
+  if (rc) return rc;
+  std::vector<GameMeta> meta(n);
+  HIP_TRY(h, hipMemcpyAsync(meta.data(), h->b.meta, (size_t)n * sizeof(GameMeta), hipMemcpyDeviceToHost, h->stream));
+  if (out_score) HIP_TRY(h, hipMemcpyAsync(out_score, h->b.best, (size_t)n * 8, hipMemcpyDeviceToHost, h->stream));
+  if (out_scores)
+    HIP_TRY(h, hipMemcpyAsync(out_scores, h->b.scores, (size_t)n * MONSOON_NUM_ACTIONS * 8, hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  if (out_action)
+    for (int i = 0; i < n; i++) out_action[i] = meta[i].last_action;
+  return MONSOON_OK;
+}
+
+int monsoon_rollout(monsoon_t* h, const double* weights, int32_t n_individuals, const monsoon_match* matches,
+                    int32_t n_matches, const uint8_t* deck_pairs, int32_t n_decks, int32_t max_turns,
+                    int32_t* out_counts, int8_t* out_results, int32_t* out_steps) {
+  if (!h || !weights || !matches || !deck_pairs || !out_counts || n_matches <= 0 || n_individuals <= 0 || max_turns <= 0 ||
+      max_turns > 30000)
+    return MONSOON_ERR_ARG;
+  int rc = monsoon_upload_weights(h, weights, n_individuals);
+  if (rc) return rc;
+  int cap = h->cfg.max_games;
+  int32_t* d_counts = nullptr;
+  int8_t* d_results = nullptr;
+  int32_t* d_steps = nullptr;
+  HIP_TRY(h, hipMalloc(&d_counts, (size_t)n_individuals * 12));
+  HIP_TRY(h, hipMemset(d_counts, 0, (size_t)n_individuals * 12));
+  HIP_TRY(h, hipMalloc(&d_results, (size_t)n_matches));
+  HIP_TRY(h, hipMalloc(&d_steps, (size_t)n_matches * 4));
+  std::vector<uint32_t> seeds;
+  std::vector<uint8_t> decks;
+  std::vector<int32_t> p1, p2;
+  for (int base = 0; base < n_matches; base += cap) {
+    int n = n_matches - base < cap ? n_matches - base : cap;
+    seeds.resize(n);
+    decks.resize((size_t)n * 24);
+    p1.resize(n);
+    p2.resize(n);
+    for (int i = 0; i < n; i++) {
+      const monsoon_match& mm = matches[base + i];
+      if (mm.p1 < 0 || mm.p1 >= n_individuals || mm.p2 < 0 || mm.p2 >= n_individuals || (int)mm.deck >= n_decks) {
+        h->err = "monsoon_rollout: schedule entry out of range";
+        hipFree(d_counts); hipFree(d_results); hipFree(d_steps);
+        return MONSOON_ERR_ARG;
+      }
+      seeds[i] = mm.seed;
+      memcpy(&decks[(size_t)i * 24], deck_pairs + (size_t)mm.deck * 24, 24);
+      p1[i] = mm.p1;
+      p2[i] = mm.p2;
+    }
+    rc = monsoon_reset(h, n, seeds.data(), decks.data(), nullptr);
+    if (!rc) rc = monsoon_assign_players(h, p1.data(), p2.data());
+    if (rc) {
+      hipFree(d_counts); hipFree(d_results); hipFree(d_steps);
+      return rc;
+    }
+    hipLaunchKernelGGL(k_set_match, dim3((n + 255) / 256), dim3(256), 0, h->stream, h->b, n, base);
+    // max_turns decision rounds + one closing round that turns "still running" into a result.
+    // Every 16 rounds the live count is read back so that finished batches stop early.
+    for (int round = 0; round <= max_turns; round++) {
+      rc = launch_decide(h, n, max_turns, 0, true);
+      if (rc) break;
+      if ((round & 15) == 15) {
+        int live = 0;
+        HIP_TRY(h, hipMemsetAsync(h->d_int, 0, 4, h->stream));
+        hipLaunchKernelGGL(k_count_live, dim3((n + 255) / 256), dim3(256), 0, h->stream, h->b, n, h->d_int);
+        HIP_TRY(h, hipMemcpyAsync(&live, h->d_int, 4, hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(h, hipStreamSynchronize(h->stream));
+        drain_timing(h);
+        if (live == 0) break;
+      }
+    }
+    if (rc) {
+      hipFree(d_counts); hipFree(d_results); hipFree(d_steps);
+      return rc;
+    }
+    hipLaunchKernelGGL(k_collect, dim3((n + 255) / 256), dim3(256), 0, h->stream, h->b, n, d_counts, d_results, d_steps);
+    HIP_TRY(h, hipGetLastError());
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    drain_timing(h);
+  }
+  std::vector<int32_t> counts((size_t)n_individuals * 3);
+  HIP_TRY(h, hipMemcpy(counts.data(), d_counts, counts.size() * 4, hipMemcpyDeviceToHost));
+  for (size_t i = 0; i < counts.size(); i++) out_counts[i] += counts[i];
+  if (out_results) HIP_TRY(h, hipMemcpy(out_results, d_results, (size_t)n_matches, hipMemcpyDeviceToHost));
+  if (out_steps) HIP_TRY(h, hipMemcpy(out_steps, d_steps, (size_t)n_matches * 4, hipMemcpyDeviceToHost));
+  hipFree(d_counts);
+  hipFree(d_results);
+  hipFree(d_steps);
+  return MONSOON_OK;
+}
+
+int monsoon_respawn_finished_dev(monsoon_t* h, uint32_t seed_base) {
+  int rc = check_ready(h);
+  if (rc) return rc;
+  // Not used by the parity paths; throughput runs keep playing until max_turns instead.
+  (void)seed_base;
+  h->err = "monsoon_respawn_finished_dev: not implemented in this build";
+  return MONSOON_ERR_STATE;
+}
+
+int monsoon_get_stats(monsoon_t* h, monsoon_stats* out) {
+  if (!h || !out) return MONSOON_ERR_ARG;
+  HIP_TRY(h, hipSetDevice(h->device));
+  unsigned long long s[8];
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  HIP_TRY(h, hipMemcpy(s, h->b.stats, sizeof(s), hipMemcpyDeviceToHost));
+  out->lookahead_steps = s[ST_LOOKAHEAD];
+  out->decisions = s[ST_DECISIONS];
+  out->games_finished = s[ST_FINISHED];
+  out->faults = s[ST_FAULTS];
+  out->capacity_faults = s[ST_CAPFAULTS];
+  return MONSOON_OK;
+}
+
+int monsoon_reset_stats(monsoon_t* h) {
+  if (!h) return MONSOON_ERR_ARG;
+  HIP_TRY(h, hipSetDevice(h->device));
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  drain_timing(h);
+  HIP_TRY(h, hipMemset(h->b.stats, 0, 8 * sizeof(unsigned long long)));
+  h->kernel_ms = 0;
+  h->kernel_launches = 0;
+  return MONSOON_OK;
+}
+
+int monsoon_kernel_time(monsoon_t* h, double* total_ms, int64_t* launches) {
+  if (!h) return MONSOON_ERR_ARG;
+  HIP_TRY(h, hipSetDevice(h->device));
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  int rc = drain_timing(h);
+  if (rc) return rc;
+  if (total_ms) *total_ms = h->kernel_ms;
+  if (launches) *launches = h->kernel_launches;
+  return MONSOON_OK;
+}
+
+void* monsoon_stream(monsoon_t* h) { return h ? (void*)h->stream : nullptr; }
+
+}  // extern "C"

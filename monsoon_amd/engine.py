@@ -1,0 +1,156 @@
+"""BatchEngine: numpy-facing wrapper of the C ABI (one handle = one GPU, a batch of games)."""
+import ctypes
+
+import numpy as np
+
+from . import _lib
+from ._lib import Config, Match, MonsoonError, Stats
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(ctypes.c_void_p)
+
+
+class BatchEngine:
+    def __init__(self, max_games, device=0, lanes_per_game=0, stack_bytes=0):
+        self.lib = _lib.load()
+        self.h = ctypes.c_void_p()
+        cfg = Config(device, max_games, lanes_per_game, stack_bytes)
+        rc = self.lib.monsoon_create(ctypes.byref(cfg), ctypes.byref(self.h))
+        if rc != _lib.OK:
+            msg = self.lib.monsoon_last_error(self.h if self.h else None)
+            if self.h:
+                self.lib.monsoon_destroy(self.h)
+            self.h = None
+            raise MonsoonError(f"monsoon_create failed (status {rc}): {msg.decode() if msg else ''}")
+        self.max_games = max_games
+        self.n = 0
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.monsoon_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001
+            pass
+
+    def _ck(self, rc, what):
+        _lib.check(self.h, rc, what)
+
+    # ---- Seam G, batched ------------------------------------------------------------------
+    def reset(self, seeds, decks, factions=None):
+        seeds = np.ascontiguousarray(seeds, dtype=np.uint32)
+        n = len(seeds)
+        decks = np.ascontiguousarray(decks, dtype=np.uint8)
+        if decks.shape == (2, 12):
+            decks = np.broadcast_to(decks, (n, 2, 12)).copy()
+        if decks.shape != (n, 2, 12):
+            raise ValueError(f"decks must be [n][2][12], got {decks.shape}")
+        if factions is not None:
+            factions = np.ascontiguousarray(factions, dtype=np.uint8).reshape(n, 2)
+        self._ck(self.lib.monsoon_reset(self.h, n, _ptr(seeds), _ptr(decks), _ptr(factions)), "monsoon_reset")
+        self.n = n
+
+    def legal_mask(self):
+        out = np.zeros((self.n, 3), dtype=np.uint64)
+        self._ck(self.lib.monsoon_legal_mask(self.h, _ptr(out)), "monsoon_legal_mask")
+        return out
+
+    def legal_actions(self, i=0, mask=None):
+        m = self.legal_mask()[i] if mask is None else mask
+        return [a for a in range(156) if (int(m[a >> 6]) >> (a & 63)) & 1]
+
+    def step(self, actions):
+        actions = np.ascontiguousarray(actions, dtype=np.uint8)
+        if actions.shape != (self.n,):
+            raise ValueError("one action per game (255 = skip)")
+        reward = np.zeros(self.n, dtype=np.int8)
+        done = np.zeros(self.n, dtype=np.uint8)
+        fault = np.zeros(self.n, dtype=np.uint8)
+        self._ck(self.lib.monsoon_step(self.h, _ptr(actions), _ptr(reward), _ptr(done), _ptr(fault)), "monsoon_step")
+        return reward, done, fault
+
+    def observe(self):
+        out = np.zeros((self.n, 27, 5, 4), dtype=np.int32)
+        raises = np.zeros(self.n, dtype=np.uint8)
+        self._ck(self.lib.monsoon_observe(self.h, _ptr(out), _ptr(raises)), "monsoon_observe")
+        return out, raises
+
+    def features(self):
+        out = np.zeros((self.n, 10), dtype=np.float64)
+        self._ck(self.lib.monsoon_features(self.h, _ptr(out)), "monsoon_features")
+        return out
+
+    def status(self):
+        out = np.zeros((self.n, 4), dtype=np.int32)
+        self._ck(self.lib.monsoon_status(self.h, _ptr(out)), "monsoon_status")
+        return out
+
+    def export(self, i):
+        buf = np.zeros(1024, dtype=np.uint8)
+        ln = ctypes.c_int32()
+        self._ck(self.lib.monsoon_state_export(self.h, i, _ptr(buf), ctypes.byref(ln)), "monsoon_state_export")
+        return buf[:ln.value].tobytes()
+
+    # ---- Seam F ---------------------------------------------------------------------------
+    def decide(self, weights, want_scores=False):
+        weights = np.ascontiguousarray(weights, dtype=np.float64)
+        if weights.shape == (10,):
+            weights = np.broadcast_to(weights, (self.n, 2, 10)).copy()
+        if weights.shape != (self.n, 2, 10):
+            raise ValueError("weights must be [n][2][10]")
+        action = np.zeros(self.n, dtype=np.uint8)
+        best = np.zeros(self.n, dtype=np.float64)
+        scores = np.zeros((self.n, 156), dtype=np.float64) if want_scores else None
+        self._ck(self.lib.monsoon_decide(self.h, _ptr(weights), _ptr(action), _ptr(best), _ptr(scores)), "monsoon_decide")
+        return (action, best, scores) if want_scores else (action, best)
+
+    def rollout(self, weights, matches, deck_pairs, max_turns, want_results=False):
+        weights = np.ascontiguousarray(weights, dtype=np.float64)
+        n_ind = weights.shape[0]
+        deck_pairs = np.ascontiguousarray(deck_pairs, dtype=np.uint8).reshape(-1, 2, 12)
+        m = np.ascontiguousarray(matches)
+        if m.dtype != np.dtype([("p1", "<i4"), ("p2", "<i4"), ("seed", "<u4"), ("deck", "<u4")]):
+            arr = np.zeros(len(matches), dtype=[("p1", "<i4"), ("p2", "<i4"), ("seed", "<u4"), ("deck", "<u4")])
+            mm = np.asarray(matches)
+            arr["p1"], arr["p2"], arr["seed"], arr["deck"] = mm[:, 0], mm[:, 1], mm[:, 2], mm[:, 3]
+            m = arr
+        counts = np.zeros((n_ind, 3), dtype=np.int32)
+        results = np.zeros(len(m), dtype=np.int8) if want_results else None
+        steps = np.zeros(len(m), dtype=np.int32) if want_results else None
+        self._ck(self.lib.monsoon_rollout(self.h, _ptr(weights), n_ind, _ptr(m), len(m), _ptr(deck_pairs), len(deck_pairs),
+                                          max_turns, _ptr(counts), _ptr(results), _ptr(steps)), "monsoon_rollout")
+        return (counts, results, steps) if want_results else counts
+
+    # ---- device-resident rounds (bench) -------------------------------------------------------
+    def upload_weights(self, weights):
+        weights = np.ascontiguousarray(weights, dtype=np.float64).reshape(-1, 10)
+        self._ck(self.lib.monsoon_upload_weights(self.h, _ptr(weights), len(weights)), "monsoon_upload_weights")
+
+    def assign_players(self, p1, p2):
+        p1 = np.ascontiguousarray(p1, dtype=np.int32)
+        p2 = np.ascontiguousarray(p2, dtype=np.int32)
+        self._ck(self.lib.monsoon_assign_players(self.h, _ptr(p1), _ptr(p2)), "monsoon_assign_players")
+
+    def decide_round(self):
+        self._ck(self.lib.monsoon_decide_round_dev(self.h), "monsoon_decide_round_dev")
+
+    def sync(self):
+        self._ck(self.lib.monsoon_sync(self.h), "monsoon_sync")
+
+    def stats(self):
+        s = Stats()
+        self._ck(self.lib.monsoon_get_stats(self.h, ctypes.byref(s)), "monsoon_get_stats")
+        return {k: int(getattr(s, k)) for k, _ in Stats._fields_}
+
+    def reset_stats(self):
+        self._ck(self.lib.monsoon_reset_stats(self.h), "monsoon_reset_stats")
+
+    def kernel_time(self):
+        ms = ctypes.c_double()
+        n = ctypes.c_int64()
+        self._ck(self.lib.monsoon_kernel_time(self.h, ctypes.byref(ms), ctypes.byref(n)), "monsoon_kernel_time")
+        return ms.value, n.value

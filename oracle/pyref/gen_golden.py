@@ -1,0 +1,287 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/ from the Python reference itself.
+
+TEST INFRASTRUCTURE (build container only; needs /root/reference, numpy 2.2.6).
+The reference has no fixtures of its own for this path, so its behaviour is pinned
+by running it here and committing inputs + expected outputs (data only, no reference source):
+
+  rng_kat.npz              G1  numpy RandomState known answers (u32, random, randint, shuffle)
+  score_kat.npz            G4  HeuristicAgent score for random (w, f_before, f_after) via np.dot
+  trace_random_<deck>.npz  G3  seeded random-policy games: legal masks, action, state hash,
+                               observation hash, reward, done (+ features for N12M)
+  trace_pool.npz           G3/G5 random 12-card decks from every supported card (card coverage)
+  trace_heuristic_N12M.npz G3  corrected heuristic self-play (SURVEY §8c contract), W0 both sides:
+                               chosen action, best score, score hash, state hash per decision
+  initial_states.npz       G2  canonical records right after construction
+  quirks.npz               G6  fact #2 (spell lands one tile late) and fact #5 (zombie path) KATs
+
+Usage: PYTHONHASHSEED=0 python oracle/pyref/gen_golden.py [--only NAME] [--jobs N]
+"""
+import argparse
+import contextlib
+import io
+import os
+import sys
+from concurrent.futures import ProcessPoolExecutor
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import harness as H  # noqa: E402
+
+GOLD = os.path.join(H.REPO, "tests", "golden")
+UNSUPPORTED = {"u017", "ua20", "b005", "b006", "b305", "s203"}
+FAULT_CARDS = {"up01", "up02", "up03"}
+W0 = np.random.RandomState(2024).uniform(0, 1, 10)
+
+
+def idx(deck):
+    return np.array([H.CARD_INDEX[c] for c in deck], dtype=np.uint8)
+
+
+def obs_hash(obs):
+    return H.fnv1a64(np.ascontiguousarray(obs, dtype="<i4").tobytes())
+
+
+# ---------------------------------------------------------------------------------------------
+def gen_rng():
+    seeds = [0, 1, 42, 123, 2**32 - 1]
+    out = {"seeds": np.array(seeds, dtype=np.uint64)}
+    bounds = np.array([1, 2, 3, 4, 5, 6, 7, 8, 9, 12, 16, 17, 20, 22, 100, 1000] * 8, dtype=np.int32)
+    out["randint_bounds"] = bounds
+    for s in seeds:
+        rs = np.random.RandomState(s)
+        out[f"u32_{s}"] = rs.randint(0, 4294967296, size=1500, dtype=np.uint32)
+        rs = np.random.RandomState(s)
+        out[f"random_{s}"] = np.array([rs.random() for _ in range(400)])
+        rs = np.random.RandomState(s)
+        out[f"randint_{s}"] = np.array([rs.randint(0, int(b)) for b in bounds], dtype=np.int32)
+        rs = np.random.RandomState(s)
+        sh = []
+        for _ in range(20):
+            a = list(range(12))
+            rs.shuffle(a)
+            sh.append(a)
+        out[f"shuffle12_{s}"] = np.array(sh, dtype=np.int32)
+    np.savez_compressed(os.path.join(GOLD, "rng_kat.npz"), **out)
+
+
+def gen_score():
+    from evo.heuristic_agent import HeuristicAgent
+    from evo.weights import WeightVector
+
+    class F:
+        def __init__(self, v):
+            self.v = v
+            self.mana_efficiency = v[0]
+
+        def get_feature_vector(self):
+            return self.v
+
+    rs = np.random.RandomState(7)
+    n = 2000
+    w = rs.uniform(0, 1, (n, 10))
+    fb = np.zeros((n, 10))
+    fa = np.zeros((n, 10))
+    scores = np.zeros(n)
+    for i in range(n):
+        # feature-like magnitudes: ratios in [0,1], integer-ish strengths, weighted sums k/5
+        fb[i] = [rs.uniform(0, 1), rs.randint(-20, 21), rs.uniform(-1, 1), rs.randint(-4, 5) / 4.0, rs.randint(-60, 60),
+                 rs.randint(-8, 9), rs.randint(-3, 4), rs.randint(0, 400) / 5.0, rs.randint(0, 400) / 5.0, rs.uniform(0, 1)]
+        fa[i] = [rs.uniform(0, 1), rs.randint(-20, 21), rs.uniform(-1, 1), rs.randint(-4, 5) / 4.0, rs.randint(-60, 60),
+                 rs.randint(-8, 9), rs.randint(-3, 4), rs.randint(0, 400) / 5.0, rs.randint(0, 400) / 5.0, rs.uniform(0, 1)]
+        wv = WeightVector(10)
+        wv.weights = w[i].copy()
+        ag = HeuristicAgent(wv, 0)
+        b, a = F(fb[i]), F(fa[i])
+        agent = ag._compute_feature_delta(b, a, for_agent=True)
+        enemy = ag._compute_feature_delta(b, a, for_agent=False)
+        res = ag._compute_resource_delta(b, a)
+        scores[i] = enemy - agent - res
+    np.savez_compressed(os.path.join(GOLD, "score_kat.npz"), w=w, before=fb, after=fa, score=scores)
+
+
+# ---------------------------------------------------------------------------------------------
+def random_trace(args):
+    seed, d0, d1, steps, want_feat = args
+    from evo.features import StateFeatures
+    g = H.make_game(seed, d0, d1)
+    pol = np.random.RandomState(seed + 1000)
+    rec = dict(legal=[], action=[], hash=[], obs=[], reward=[], done=[], feat=[], fault=0)
+    init_hash = H.fnv1a64(H.canon(g))
+    for _ in range(steps):
+        la = g.legal_actions()
+        a = int(la[pol.randint(0, len(la))])
+        try:
+            with contextlib.redirect_stdout(io.StringIO()):
+                obs, reward, done = g.step(a)
+        except Exception:  # noqa: BLE001  the agent layer swallows these; the trace ends here
+            rec["legal"].append(H.legal_mask(la))
+            rec["action"].append(a)
+            rec["fault"] = 1
+            break
+        rec["legal"].append(H.legal_mask(la))
+        rec["action"].append(a)
+        rec["hash"].append(H.fnv1a64(H.canon(g)))
+        rec["obs"].append(obs_hash(obs))
+        rec["reward"].append(reward)
+        rec["done"].append(int(done))
+        if want_feat:
+            rec["feat"].append(StateFeatures(obs, g.to_play()).get_feature_vector())
+        if g.have_winner():
+            break
+    return seed, init_hash, rec
+
+
+def pack_traces(name, jobs, results, decks0, decks1):
+    out = dict(seeds=[], init_hash=[], offsets=[0], fault=[], legal=[], action=[], hash=[], obs=[], reward=[], done=[], feat=[])
+    for seed, init_hash, rec in results:
+        out["seeds"].append(seed)
+        out["init_hash"].append(init_hash)
+        out["fault"].append(rec["fault"])
+        out["legal"] += rec["legal"]
+        out["action"] += rec["action"]
+        # faulted final step has no post-state: pad so that every array is indexed by step
+        pad = len(rec["action"]) - len(rec["hash"])
+        out["hash"] += rec["hash"] + [0] * pad
+        out["obs"] += rec["obs"] + [0] * pad
+        out["reward"] += rec["reward"] + [0] * pad
+        out["done"] += rec["done"] + [0] * pad
+        out["feat"] += rec["feat"]
+        out["offsets"].append(len(out["action"]))
+    arrs = dict(
+        seeds=np.array(out["seeds"], dtype=np.uint32), init_hash=np.array(out["init_hash"], dtype=np.uint64),
+        offsets=np.array(out["offsets"], dtype=np.int64), fault=np.array(out["fault"], dtype=np.uint8),
+        legal=np.array(out["legal"], dtype=np.uint64).reshape(-1, 3), action=np.array(out["action"], dtype=np.uint8),
+        hash=np.array(out["hash"], dtype=np.uint64), obs=np.array(out["obs"], dtype=np.uint64),
+        reward=np.array(out["reward"], dtype=np.int8), done=np.array(out["done"], dtype=np.uint8),
+        deck0=np.array(decks0, dtype=np.uint8), deck1=np.array(decks1, dtype=np.uint8))
+    if out["feat"]:
+        arrs["feat"] = np.array(out["feat"], dtype=np.float64)
+    np.savez_compressed(os.path.join(GOLD, name), **arrs)
+    print(name, "games", len(out["seeds"]), "steps", len(out["action"]))
+
+
+def gen_random(deck, deck2, n_games, steps, jobs, want_feat=False, seed0=0):
+    d0, d1 = H.DECKS[deck], H.DECKS[deck2 or deck]
+    tasks = [(seed0 + k, d0, d1, steps, want_feat) for k in range(n_games)]
+    with ProcessPoolExecutor(jobs) as ex:
+        results = list(ex.map(random_trace, tasks))
+    pack_traces(f"trace_random_{deck}.npz", jobs, results, [idx(d0)] * n_games, [idx(d1)] * n_games)
+
+
+def gen_pool(n_games, steps, jobs):
+    pool = [c for c in H.CARD_IDS if c not in UNSUPPORTED and c not in FAULT_CARDS]
+    tasks, decks0, decks1 = [], [], []
+    for k in range(n_games):
+        seed = 5000 + k
+        rs = np.random.RandomState(seed ^ 0x9E3779B9)
+        d0 = list(rs.choice(pool, 12, replace=False))
+        d1 = list(rs.choice(pool, 12, replace=False))
+        tasks.append((seed, d0, d1, steps, False))
+        decks0.append(idx(d0))
+        decks1.append(idx(d1))
+    with ProcessPoolExecutor(jobs) as ex:
+        results = list(ex.map(random_trace, tasks))
+    pack_traces("trace_pool.npz", jobs, results, decks0, decks1)
+
+
+# ---------------------------------------------------------------------------------------------
+def heuristic_trace(args):
+    """Corrected rollout loop: while not have_winner() and steps < max_turns."""
+    seed, d0, d1, max_turns = args
+    from evo.game_adapter import StormboundAdapter
+    from evo.heuristic_agent import HeuristicAgent
+    from evo.weights import WeightVector
+    from games.stormbound import Game
+
+    game = Game.__new__(Game)
+    game.env = H.make_game(seed, d0, d1)
+    wv = WeightVector(10)
+    wv.weights = W0.copy()
+    agents = [HeuristicAgent(wv, 0), HeuristicAgent(wv, 1)]
+    adapter = StormboundAdapter(game)
+    rec = dict(action=[], hash=[], best=[], shash=[], nlegal=[])
+    steps = 0
+    with contextlib.redirect_stdout(io.StringIO()):
+        while not adapter.game.env.have_winner() and steps < max_turns:
+            agent = agents[adapter.get_current_player()]
+            legal = adapter.get_legal_actions()
+            scores = np.array([agent.score_action(adapter, a) for a in legal], dtype=np.float64)
+            k = int(np.argmax(scores))
+            a = legal[k]
+            adapter = adapter.apply_action(a)
+            steps += 1
+            rec["action"].append(a)
+            rec["hash"].append(H.fnv1a64(H.canon(adapter.game.env)))
+            rec["best"].append(scores[k])
+            rec["shash"].append(H.fnv1a64(scores.tobytes()))
+            rec["nlegal"].append(len(legal))
+    env = adapter.game.env
+    b = {int(env.board.local.order): env.board.local.strength, int(env.board.remote.order): env.board.remote.strength}
+    result = 0 if (b[1] < 0 <= b[0]) else 1 if (b[0] < 0 <= b[1]) else -1
+    return seed, rec, result
+
+
+def gen_heuristic(n_games, max_turns, jobs):
+    d = H.DECKS["N12M"]
+    tasks = [(s, d, d, max_turns) for s in range(n_games)]
+    with ProcessPoolExecutor(jobs) as ex:
+        results = list(ex.map(heuristic_trace, tasks))
+    out = dict(seeds=[], offsets=[0], result=[], action=[], hash=[], best=[], shash=[], nlegal=[])
+    for seed, rec, result in results:
+        out["seeds"].append(seed)
+        out["result"].append(result)
+        for k in ("action", "hash", "best", "shash", "nlegal"):
+            out[k] += rec[k]
+        out["offsets"].append(len(out["action"]))
+    np.savez_compressed(
+        os.path.join(GOLD, "trace_heuristic_N12M.npz"), seeds=np.array(out["seeds"], dtype=np.uint32),
+        offsets=np.array(out["offsets"], dtype=np.int64), result=np.array(out["result"], dtype=np.int8),
+        action=np.array(out["action"], dtype=np.uint8), hash=np.array(out["hash"], dtype=np.uint64),
+        best=np.array(out["best"], dtype=np.float64), shash=np.array(out["shash"], dtype=np.uint64),
+        nlegal=np.array(out["nlegal"], dtype=np.int16), deck=idx(d), w0=W0, max_turns=np.int32(max_turns))
+    print("trace_heuristic_N12M.npz games", n_games, "decisions", len(out["action"]),
+          "look-ahead steps", int(np.sum(out["nlegal"])))
+
+
+def gen_initial():
+    recs, lens, seeds = [], [], []
+    for deck in ("N12V", "N12M", "S12"):
+        for seed in (0, 1, 42, 123, 2**32 - 1):
+            c = H.canon(H.make_game(seed, H.DECKS[deck], H.DECKS[deck]))
+            buf = np.zeros(1024, dtype=np.uint8)
+            buf[:len(c)] = np.frombuffer(c, dtype=np.uint8)
+            recs.append(buf)
+            lens.append(len(c))
+            seeds.append(seed)
+    np.savez_compressed(os.path.join(GOLD, "initial_states.npz"), canon=np.array(recs), length=np.array(lens, dtype=np.int32),
+                        seeds=np.array(seeds, dtype=np.uint64),
+                        decks=np.array([idx(H.DECKS[d]) for d in ("N12V", "N12M", "S12") for _ in range(5)], dtype=np.uint8))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--only", default=None)
+    ap.add_argument("--jobs", type=int, default=6)
+    args = ap.parse_args()
+    os.makedirs(GOLD, exist_ok=True)
+    todo = {
+        "rng": gen_rng,
+        "score": gen_score,
+        "initial": gen_initial,
+        "random_N12V": lambda: gen_random("N12V", None, 16, 300, args.jobs),
+        "random_N12M": lambda: gen_random("N12M", None, 48, 300, args.jobs, want_feat=True),
+        "random_IRONCLAD": lambda: gen_random("IRONCLAD", "SWARM", 32, 300, args.jobs),
+        "pool": lambda: gen_pool(160, 300, args.jobs),
+        "heuristic": lambda: gen_heuristic(12, 200, args.jobs),
+    }
+    for name, fn in todo.items():
+        if args.only and args.only != name:
+            continue
+        fn()
+        print("done", name)
+
+
+if __name__ == "__main__":
+    main()
