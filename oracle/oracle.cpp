@@ -15,6 +15,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
+#include <thread>
 #include <vector>
 
 #include "../monsoon_amd/csrc/canon.h"
@@ -247,6 +249,31 @@ int orc_rollout(void* h, int gi, const double* w_p1, const double* w_p2, int max
   if (n_lookahead) *n_lookahead = g.lookahead_steps;
   if (fault_out) *fault_out = fault;
   return result;
+}
+
+// Multi-threaded batch of rollouts (bench.py cpu_baseline leg): games [0, n) of the handle must
+// have been reset; the same weight vector plays both sides.  Returns total look-ahead steps.
+uint64_t orc_rollout_batch(void* h, int n, const double* w, int max_turns, int n_threads, int8_t* results,
+                           int32_t* steps, uint64_t* hashes) {
+  std::atomic<int> next(0);
+  std::atomic<uint64_t> total(0);
+  auto worker = [&]() {
+    for (;;) {
+      int i = next.fetch_add(1);
+      if (i >= n) break;
+      int ns = 0, fl = 0;
+      uint64_t nl = 0;
+      int r = orc_rollout(h, i, w, w, max_turns, nullptr, nullptr, &ns, &nl, &fl);
+      if (results) results[i] = (int8_t)r;
+      if (steps) steps[i] = ns;
+      if (hashes) hashes[i] = orc_canon_hash(h, i);
+      total += nl;
+    }
+  };
+  std::vector<std::thread> th;
+  for (int t = 0; t < n_threads; t++) th.emplace_back(worker);
+  for (auto& t : th) t.join();
+  return total.load();
 }
 
 // ---- RNG known-answer entry points (tests/golden/rng_kat.npz) ---------------------------------

@@ -43,6 +43,9 @@ def lib():
         L.orc_rollout.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p,
                                   ctypes.c_void_p, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_uint64),
                                   ctypes.POINTER(ctypes.c_int)]
+        L.orc_rollout_batch.restype = ctypes.c_uint64
+        L.orc_rollout_batch.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_int,
+                                        ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
         L.orc_score.restype = ctypes.c_double
         L.orc_score.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
         L.orc_rng_u32.argtypes = [ctypes.c_uint32, ctypes.c_int, ctypes.c_void_p]
@@ -143,3 +146,12 @@ class Oracle:
             out["actions"] = acts[:ns.value]
             out["hashes"] = hashes[:ns.value]
         return out
+
+    def rollout_batch(self, n, w, max_turns, threads):
+        """Rollouts of games [0, n) (same weights both sides) on `threads` host threads."""
+        w = np.ascontiguousarray(w, dtype=np.float64)
+        results = np.zeros(n, dtype=np.int8)
+        steps = np.zeros(n, dtype=np.int32)
+        hashes = np.zeros(n, dtype=np.uint64)
+        total = self.L.orc_rollout_batch(self.h, n, _p(w), max_turns, threads, _p(results), _p(steps), _p(hashes))
+        return int(total), results, steps, hashes
