@@ -91,6 +91,10 @@ int monsoon_status(monsoon_t* h, int32_t* out);
  * bit-exactness tests.  buf must hold 1024 bytes. */
 int monsoon_state_export(monsoon_t* h, int32_t idx, uint8_t* buf, int32_t* len);
 
+/* FNV-1a 64 of the canonical record of every game: out[n].  Lets a caller compare a whole batch
+ * against a replay without exporting 65 536 records one by one. */
+int monsoon_state_hash(monsoon_t* h, uint64_t* out);
+
 /* HeuristicAgent.select_action + adapter.apply_action for every live game
  * (evo/heuristic_agent.py:53-80, evo/game_adapter.py:320-325): 1-ply look-ahead over all legal
  * actions, score, first-max argmax, commit.  weights[n][2][10]: the weight vector of the FIRST
@@ -114,8 +118,6 @@ int monsoon_upload_weights(monsoon_t* h, const double* weights, int32_t n_indivi
 int monsoon_assign_players(monsoon_t* h, const int32_t* p1, const int32_t* p2);   /* [n] indices */
 int monsoon_decide_round_dev(monsoon_t* h);   /* asynchronous on the handle's stream */
 int monsoon_sync(monsoon_t* h);
-/* Re-seed finished games in place (keeps the batch at full occupancy for throughput runs). */
-int monsoon_respawn_finished_dev(monsoon_t* h, uint32_t seed_base);
 
 int monsoon_get_stats(monsoon_t* h, monsoon_stats* out);
 int monsoon_reset_stats(monsoon_t* h);

@@ -50,6 +50,7 @@ SIGNATURES = {
     "monsoon_features": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p]),
     "monsoon_status": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p]),
     "monsoon_state_export": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p, ctypes.POINTER(ctypes.c_int32)]),
+    "monsoon_state_hash": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p]),
     "monsoon_decide": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
     "monsoon_rollout": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p, ctypes.c_int32,
                                        ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p,
@@ -58,7 +59,6 @@ SIGNATURES = {
     "monsoon_assign_players": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
     "monsoon_decide_round_dev": (ctypes.c_int, [ctypes.c_void_p]),
     "monsoon_sync": (ctypes.c_int, [ctypes.c_void_p]),
-    "monsoon_respawn_finished_dev": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_uint32]),
     "monsoon_get_stats": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(Stats)]),
     "monsoon_reset_stats": (ctypes.c_int, [ctypes.c_void_p]),
     "monsoon_kernel_time": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int64)]),

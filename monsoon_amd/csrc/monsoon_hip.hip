@@ -295,6 +295,21 @@ __global__ void __launch_bounds__(64) k_export(DevBuffers b, int g, uint8_t* out
   *len = canon_record(e, nx, out);
 }
 
+__global__ void __launch_bounds__(64) k_hash(DevBuffers b, int n, uint64_t* out) {
+  __shared__ ApiLds lds;
+  int g = blockIdx.x * 64 + threadIdx.x;
+  if (g >= n) return;
+  Engine<LdsMem> e;
+  e.m.base = (MSB_AS_LDS uint32_t*)lds.w + threadIdx.x;
+  e.m.stride = 64;
+  api_load(e.m.base, b.state + (size_t)g * SW);
+  RngView v = make_view(b, g, b.meta[g].rng);
+  uint32_t nx = v.next_u32();
+  uint8_t rec[CANON_MAX];
+  int len = canon_record(e, nx, rec);
+  out[g] = fnv1a64(rec, len);
+}
+
 // ------------------------------------------------------------------------------------------------
 // Hot kernel: one decision (look-ahead + score + argmax + commit) per game, one wavefront per game.
 // ------------------------------------------------------------------------------------------------
@@ -780,6 +795,18 @@ int monsoon_state_export(monsoon_t* h, int32_t idx, uint8_t* buf, int32_t* len) 
   return MONSOON_OK;
 }
 
+int monsoon_state_hash(monsoon_t* h, uint64_t* out) {
+  int rc = check_ready(h);
+  if (rc) return rc;
+  if (!out) return MONSOON_ERR_ARG;
+  int n = h->n;
+  hipLaunchKernelGGL(k_hash, dim3((n + 63) / 64), dim3(64), 0, h->stream, h->b, n, h->d_masks);
+  HIP_TRY(h, hipGetLastError());
+  HIP_TRY(h, hipMemcpyAsync(out, h->d_masks, (size_t)n * 8, hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  return MONSOON_OK;
+}
+
 int monsoon_upload_weights(monsoon_t* h, const double* weights, int32_t n_individuals) {
   if (!h || !weights || n_individuals <= 0) return MONSOON_ERR_ARG;
   HIP_TRY(h, hipSetDevice(h->device));
@@ -973,15 +1000,6 @@ int monsoon_rollout(monsoon_t* h, const double* weights, int32_t n_individuals, 
   hipFree(d_results);
   hipFree(d_steps);
   return MONSOON_OK;
-}
-
-int monsoon_respawn_finished_dev(monsoon_t* h, uint32_t seed_base) {
-  int rc = check_ready(h);
-  if (rc) return rc;
-  // Not used by the parity paths; throughput runs keep playing until max_turns instead.
-  (void)seed_base;
-  h->err = "monsoon_respawn_finished_dev: not implemented in this build";
-  return MONSOON_ERR_STATE;
 }
 
 int monsoon_get_stats(monsoon_t* h, monsoon_stats* out) {

@@ -95,6 +95,11 @@ class BatchEngine:
         self._ck(self.lib.monsoon_state_export(self.h, i, _ptr(buf), ctypes.byref(ln)), "monsoon_state_export")
         return buf[:ln.value].tobytes()
 
+    def state_hash(self):
+        out = np.zeros(self.n, dtype=np.uint64)
+        self._ck(self.lib.monsoon_state_hash(self.h, _ptr(out)), "monsoon_state_hash")
+        return out
+
     # ---- Seam F ---------------------------------------------------------------------------
     def decide(self, weights, want_scores=False):
         weights = np.ascontiguousarray(weights, dtype=np.float64)

@@ -1,0 +1,171 @@
+"""FitnessEvaluator -- Seam F: evaluate_population(population, generation) -> List[float]
+(mirror of evo/fitness.py:18-259, the only call the GA driver makes into the hot path,
+evo/evolution.py:88).
+
+The reference's rollout loop is dead code (StormboundAdapter.is_terminal is always True,
+evo/game_adapter.py:339-342 -> every game is scored as a player-1 win in 0 steps); it is kept as
+mode="as_written".  mode="rollout" plays the games for real under the contract of SURVEY.md §8c:
+    while not have_winner() and steps < max_turns: a = agent[to_play].select_action(); apply(a)
+    P1 wins iff P2's base < 0 <= P1's base; P2 wins iff P1's base < 0 <= P2's base; else draw;
+    a faulting committed step ends the game as a draw (evo/fitness.py:170-174, 208-210).
+All games of a generation form one schedule of (p1, p2, seed, deck) entries which the HIP engine
+plays monsoon_config.max_games at a time.  With torch.distributed initialised the schedule is
+sharded by row individual, one process per GPU, and the per-individual {wins, draws, games}
+counters are summed with one all_reduce (RCCL over xGMI on GPUs; gloo in the CPU tests).
+"""
+import time
+
+import numpy as np
+
+MATCH_DTYPE = np.dtype([("p1", "<i4"), ("p2", "<i4"), ("seed", "<u4"), ("deck", "<u4")])
+
+
+def hash32(*vals):
+    """Deterministic game seed from (generation, i, j, game) -- the reference uses Game(seed=None)
+    (evo/fitness.py:144-145), i.e. OS entropy; a reproducible build needs an explicit seed."""
+    h = 0x9E3779B9
+    for v in vals:
+        h ^= (int(v) + 0x7F4A7C15 + ((h << 6) & 0xFFFFFFFF) + (h >> 2)) & 0xFFFFFFFF
+        h = (h * 0x85EBCA6B) & 0xFFFFFFFF
+        h ^= h >> 13
+        h = (h * 0xC2B2AE35) & 0xFFFFFFFF
+        h ^= h >> 16
+    return h
+
+
+def round_robin_schedule(n_individuals, n_total_opponents, games_per_pairing, generation):
+    """evo/fitness.py:53-59,133: every individual vs every other opponent (population + hall of fame)."""
+    rows = []
+    for i in range(n_individuals):
+        for j in range(n_total_opponents):
+            if j < n_individuals and i == j:
+                continue
+            for g in range(games_per_pairing):
+                rows.append((i, j, hash32(generation, i, j, g), 0))
+    return np.array(rows, dtype=MATCH_DTYPE)
+
+
+def ring_schedule(n_individuals, games_per_individual, generation):
+    """individual i plays FIRST against (i+1+k) mod N, k = 0..games-1."""
+    rows = [(i, (i + 1 + k) % n_individuals, hash32(generation, i, k), 0)
+            for i in range(n_individuals) for k in range(games_per_individual)]
+    return np.array(rows, dtype=MATCH_DTYPE)
+
+
+def shard_by_individual(matches, n_individuals, rank, world):
+    """Contiguous blocks of row individuals per rank."""
+    lo = (n_individuals * rank) // world
+    hi = (n_individuals * (rank + 1)) // world
+    return matches[(matches["p1"] >= lo) & (matches["p1"] < hi)]
+
+
+def fitness_from_counts(counts, games_per_individual):
+    """wins + 0.5*draws, normalised (evo/fitness.py:111-113,160-166)."""
+    counts = np.asarray(counts, dtype=np.float64)
+    return [float((counts[i, 0] + 0.5 * counts[i, 1]) / games_per_individual) for i in range(len(counts))]
+
+
+class FitnessEvaluator:
+    def __init__(self, config, deck_config=None, rollout_fn=None, device=None):
+        self.config = config
+        self.deck_config = deck_config      # accepted for signature parity; decks come from config.deck
+        self.total_games = 0
+        self.total_time = 0.0
+        self.total_env_steps = 0
+        self.hall_of_fame = []
+        self.hall_of_fame_size = 5
+        self.use_hall_of_fame = True
+        self._rollout_fn = rollout_fn
+        self._device = device
+        self._engine = None
+
+    # -- device ------------------------------------------------------------------------------
+    def _hip_rollout(self, weights, matches, deck_pairs, max_turns):
+        from .engine import BatchEngine
+        if self._engine is None:
+            dev = self._device
+            if dev is None:
+                import os
+                dev = int(os.environ.get("LOCAL_RANK", "0"))
+            self._engine = BatchEngine(self.config.max_concurrent_games, device=dev, lanes_per_game=self.config.lanes_per_game)
+        before = self._engine.stats()["lookahead_steps"]
+        counts = self._engine.rollout(weights, matches, deck_pairs, max_turns)
+        self.total_env_steps += self._engine.stats()["lookahead_steps"] - before
+        return counts
+
+    @staticmethod
+    def _dist():
+        try:
+            import torch.distributed as dist
+            if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+                return dist
+        except ImportError:
+            pass
+        return None
+
+    # -- Seam F ------------------------------------------------------------------------------
+    def evaluate_population(self, population, generation=0):
+        from .cards import deck_indices
+        cfg = self.config
+        n = len(population)
+        opponents = list(population)
+        if self.use_hall_of_fame and self.hall_of_fame:
+            opponents.extend(self.hall_of_fame)
+        n_total = len(opponents)
+        start = time.time()
+        if cfg.schedule == "ring":
+            matches = ring_schedule(n, cfg.games_per_individual, generation)
+            per_individual = cfg.games_per_individual
+        else:
+            matches = round_robin_schedule(n, n_total, cfg.games_per_pairing, generation)
+            per_individual = (n_total - 1) * cfg.games_per_pairing
+        if cfg.mode == "as_written":
+            # _play_game returns 0 ("agent1 wins") without a step for every game
+            counts = np.zeros((n_total, 3), dtype=np.int64)
+            np.add.at(counts[:, 0], matches["p1"], 1)
+            np.add.at(counts[:, 2], matches["p1"], 1)
+        else:
+            weights = np.stack([np.asarray(o.weights, dtype=np.float64) for o in opponents])
+            deck = deck_indices(cfg.deck)
+            deck_pairs = np.stack([deck, deck])[None]
+            dist = self._dist()
+            mine = matches
+            if dist is not None:
+                mine = shard_by_individual(matches, n, dist.get_rank(), dist.get_world_size())
+            fn = self._rollout_fn or self._hip_rollout
+            counts = np.zeros((n_total, 3), dtype=np.int64)
+            if len(mine):
+                counts += np.asarray(fn(weights, mine, deck_pairs, cfg.max_turns), dtype=np.int64)
+            if dist is not None:
+                counts = self._all_reduce_counts(dist, counts)
+        self.total_games += len(matches)
+        self.total_time += time.time() - start
+        fitness = fitness_from_counts(counts[:n], per_individual)
+        self._update_hall_of_fame(population, fitness)
+        return fitness
+
+    @staticmethod
+    def _all_reduce_counts(dist, counts):
+        import torch
+        t = torch.from_numpy(np.ascontiguousarray(counts))
+        if dist.get_backend() == "nccl":   # RCCL: the tensor must live on this rank's GPU
+            t = t.cuda()
+        dist.all_reduce(t)   # sum over ranks; <= 48 KB at N = 4096
+        return t.cpu().numpy()
+
+    # evo/fitness.py:247-259: copies of the five best of this generation
+    def _update_hall_of_fame(self, population, fitness):
+        ranked = sorted(zip(fitness, population), key=lambda p: p[0], reverse=True)
+        self.hall_of_fame = [ind.copy() for _, ind in ranked[:self.hall_of_fame_size]]
+
+    def get_stats(self):
+        return {"total_games": self.total_games, "total_time": self.total_time,
+                "avg_time_per_game": self.total_time / max(self.total_games, 1),
+                "games_per_second": self.total_games / max(self.total_time, 1e-6),
+                "env_steps": self.total_env_steps,
+                "env_steps_per_second": self.total_env_steps / max(self.total_time, 1e-6)}
+
+    def reset_stats(self):
+        self.total_games = 0
+        self.total_time = 0.0
+        self.total_env_steps = 0

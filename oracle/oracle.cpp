@@ -210,6 +210,13 @@ uint64_t orc_canon_hash(void* h, int gi) {
   return fnv1a64(buf, n);
 }
 
+// fnv1a64 over the little-endian int32 observation bytes (0 where the observation raises)
+uint64_t orc_obs_hash(void* h, int gi) {
+  int32_t obs[540];
+  if (orc_observe(h, gi, obs)) return 0;
+  return fnv1a64((const uint8_t*)obs, sizeof(obs));
+}
+
 int orc_have_winner(void* h, int gi) {
   Game& g = ((Oracle*)h)->games[gi];
   Engine<FlatMem> e = engine(g);

@@ -13,7 +13,7 @@ by running it here and committing inputs + expected outputs (data only, no refer
   trace_heuristic_N12M.npz G3  corrected heuristic self-play (SURVEY §8c contract), W0 both sides:
                                chosen action, best score, score hash, state hash per decision
   initial_states.npz       G2  canonical records right after construction
-  quirks.npz               G6  fact #2 (spell lands one tile late) and fact #5 (zombie path) KATs
+  population_seed42.npz        GA driver: initial population + first offspring for config.seed=42
 
 Usage: PYTHONHASHSEED=0 python oracle/pyref/gen_golden.py [--only NAME] [--jobs N]
 """
@@ -260,6 +260,21 @@ def gen_initial():
                         decks=np.array([idx(H.DECKS[d]) for d in ("N12V", "N12M", "S12") for _ in range(5)], dtype=np.uint8))
 
 
+def gen_population():
+    """GA driver numerics: Population.initialize_population + generate_offspring with config.seed=42."""
+    from evo.config import EvolutionaryConfig
+    from evo.population import Population
+    cfg = EvolutionaryConfig(mu=12, lambda_=12, seed=42)
+    with contextlib.redirect_stdout(io.StringIO()):
+        pop = Population(cfg)
+        pop.initialize_population(10)
+        w0 = np.array([i.get_weights() for i in pop.individuals])
+        s0 = np.array([i.get_sigmas() for i in pop.individuals])
+        off = pop.generate_offspring()
+    np.savez_compressed(os.path.join(GOLD, "population_seed42.npz"), init_weights=w0, init_sigmas=s0,
+                        off_weights=np.array([i.get_weights() for i in off]), off_sigmas=np.array([i.get_sigmas() for i in off]))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default=None)
@@ -270,6 +285,7 @@ def main():
         "rng": gen_rng,
         "score": gen_score,
         "initial": gen_initial,
+        "population": gen_population,
         "random_N12V": lambda: gen_random("N12V", None, 16, 300, args.jobs),
         "random_N12M": lambda: gen_random("N12M", None, 48, 300, args.jobs, want_feat=True),
         "random_IRONCLAD": lambda: gen_random("IRONCLAD", "SWARM", 32, 300, args.jobs),

@@ -37,6 +37,8 @@ def lib():
         L.orc_canon.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
         L.orc_canon_hash.restype = ctypes.c_uint64
         L.orc_canon_hash.argtypes = [ctypes.c_void_p, ctypes.c_int]
+        L.orc_obs_hash.restype = ctypes.c_uint64
+        L.orc_obs_hash.argtypes = [ctypes.c_void_p, ctypes.c_int]
         L.orc_have_winner.argtypes = [ctypes.c_void_p, ctypes.c_int]
         L.orc_to_play.argtypes = [ctypes.c_void_p, ctypes.c_int]
         L.orc_decide.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
@@ -119,6 +121,9 @@ class Oracle:
 
     def canon_hash(self, i):
         return int(self.L.orc_canon_hash(self.h, i))
+
+    def obs_hash(self, i):
+        return int(self.L.orc_obs_hash(self.h, i))
 
     def have_winner(self, i):
         return bool(self.L.orc_have_winner(self.h, i))

@@ -1,0 +1,25 @@
+"""Oracle-backed stand-in for BatchEngine.rollout, for CPU tests of the host logic (Seam F,
+schedule sharding, the gloo all-reduce).  Test infrastructure only."""
+import numpy as np
+
+import oracle_lib
+
+
+def oracle_rollout_fn(weights, matches, deck_pairs, max_turns, want_results=False):
+    weights = np.ascontiguousarray(weights, dtype=np.float64)
+    deck_pairs = np.asarray(deck_pairs, dtype=np.uint8).reshape(-1, 2, 12)
+    counts = np.zeros((len(weights), 3), dtype=np.int64)
+    orc = oracle_lib.Oracle(1)
+    results = np.zeros(len(matches), dtype=np.int8)
+    steps = np.zeros(len(matches), dtype=np.int32)
+    for k, m in enumerate(matches):
+        d = deck_pairs[int(m["deck"])]
+        orc.reset(0, int(m["seed"]), d[0], d[1])
+        r = orc.rollout(0, weights[int(m["p1"])], weights[int(m["p2"])], max_turns)
+        results[k], steps[k] = r["result"], r["steps"]
+        if r["result"] == 0:
+            counts[int(m["p1"]), 0] += 1
+        elif r["result"] == -1:
+            counts[int(m["p1"]), 1] += 1
+        counts[int(m["p1"]), 2] += 1
+    return (counts, results, steps) if want_results else counts

@@ -1,0 +1,198 @@
+"""GPU parity tests (run with -m gpu on an MI355X): every call goes through the C ABI
+(libmonsoon_hip.so via ctypes).  The HIP path is compared with
+  (1) the golden vectors generated from the Python reference (tests/golden/), directly, and
+  (2) the CPU replay oracle on the same seeded inputs, up to BASELINE's full size (65 536 games).
+Integer/byte work: the bar is bit-exact (canonical state records, legal masks, observations,
+actions; float64 features and scores compared by bit pattern)."""
+import numpy as np
+import pytest
+
+import oracle_lib
+from monsoon_amd.cards import deck_indices
+
+pytestmark = pytest.mark.gpu
+
+W0 = np.random.RandomState(2024).uniform(0, 1, 10)
+
+
+@pytest.fixture(scope="module")
+def engines():
+    from monsoon_amd.engine import BatchEngine
+    cache = {}
+
+    def get(n, lanes=0):
+        key = (n, lanes)
+        if key not in cache:
+            cache[key] = BatchEngine(n, lanes_per_game=lanes)
+        return cache[key]
+    yield get
+    for e in cache.values():
+        e.close()
+
+
+def test_initial_states_vs_reference(engines, gold):
+    g = gold("initial_states.npz")
+    ok = [k for k in range(len(g["seeds"])) if k < 10]   # N12V, N12M (S12 holds s203: unsupported, refused)
+    eng = engines(16)
+    eng.reset(g["seeds"][ok].astype(np.uint32), np.stack([np.stack([g["decks"][k]] * 2) for k in ok]))
+    for j, k in enumerate(ok):
+        assert eng.export(j) == g["canon"][k][:g["length"][k]].tobytes(), k
+
+
+@pytest.mark.parametrize("name", ["trace_random_N12V.npz", "trace_random_N12M.npz", "trace_random_IRONCLAD.npz", "trace_pool.npz"])
+def test_random_policy_traces_vs_reference(engines, gold, name):
+    """Replays the reference's seeded random-policy games through monsoon_step in lockstep."""
+    g = gold(name)
+    n = len(g["seeds"])
+    eng = engines(256)
+    eng.reset(g["seeds"], np.stack([g["deck0"], g["deck1"]], axis=1))
+    assert np.array_equal(eng.state_hash(), g["init_hash"])
+    orc = oracle_lib.Oracle(n)
+    for k in range(n):
+        orc.reset(k, int(g["seeds"][k]), g["deck0"][k], g["deck1"][k])
+    off = g["offsets"]
+    lens = off[1:] - off[:-1]
+    for t in range(int(lens.max())):
+        live = np.nonzero(lens > t)[0]
+        masks = eng.legal_mask()
+        acts = np.full(n, 255, dtype=np.uint8)
+        for k in live:
+            assert np.array_equal(masks[k], g["legal"][off[k] + t]), (k, t)
+            acts[k] = g["action"][off[k] + t]
+        reward, done, fault = eng.step(acts)
+        hashes = eng.state_hash()
+        obs, raises = eng.observe()
+        for k in live:
+            i = off[k] + t
+            fo, _, _ = orc.step(k, int(acts[k]))
+            if g["fault"][k] and t == lens[k] - 1:   # the reference raised on this step
+                assert fault[k] != 0 or raises[k], (k, t)
+                continue
+            assert fault[k] == 0 and fo == 0, (k, t, fault[k])
+            assert hashes[k] == g["hash"][i], (k, t)
+            assert (reward[k], done[k]) == (g["reward"][i], g["done"][i]), (k, t)
+            assert np.array_equal(obs[k], orc.observe(k)), (k, t)
+    if "feat" in g.files:
+        feat = eng.features()
+        for k in range(n):
+            if not g["fault"][k]:
+                assert np.array_equal(feat[k].view(np.uint64), g["feat"][off[k + 1] - 1].view(np.uint64)), k
+
+
+def test_heuristic_selfplay_vs_reference(engines, gold):
+    """monsoon_decide against the reference's HeuristicAgent self-play (corrected loop): action,
+    complete score vector, best score and committed state at each of 2 400 decisions."""
+    g = gold("trace_heuristic_N12M.npz")
+    n = len(g["seeds"])
+    eng = engines(16)
+    eng.reset(g["seeds"], np.stack([g["deck"], g["deck"]]))
+    off = g["offsets"]
+    for t in range(int(g["max_turns"])):
+        action, best, scores = eng.decide(g["w0"], want_scores=True)
+        hashes = eng.state_hash()
+        for k in range(n):
+            i = off[k] + t
+            if i >= off[k + 1]:
+                continue
+            assert action[k] == g["action"][i], (k, t)
+            legal = ~np.isnan(scores[k])
+            assert int(legal.sum()) == g["nlegal"][i]
+            assert oracle_lib.fnv1a64(scores[k][legal].tobytes()) == int(g["shash"][i]), (k, t)
+            assert best[k] == g["best"][i]
+            assert hashes[k] == g["hash"][i], (k, t)
+
+
+@pytest.mark.parametrize("lanes", [16, 32, 64])
+def test_rollout_vs_oracle_2048_games(engines, lanes):
+    """All lane configurations (16 forces the multi-pass + replay path) give the oracle's games."""
+    n = 2048
+    deck = deck_indices("N12M")
+    eng = engines(n, lanes)
+    matches = np.zeros(n, dtype=[("p1", "<i4"), ("p2", "<i4"), ("seed", "<u4"), ("deck", "<u4")])
+    matches["seed"] = np.arange(n) + 100000
+    counts, results, steps = eng.rollout(W0[None], matches, np.stack([deck, deck])[None], 200, want_results=True)
+    hashes = eng.state_hash()
+    orc = oracle_lib.Oracle(n)
+    for i in range(n):
+        orc.reset(i, 100000 + i, deck, deck)
+    total, ores, osteps, ohash = orc.rollout_batch(n, W0, 200, 16)
+    assert np.array_equal(results, ores)
+    assert np.array_equal(steps, osteps)
+    assert np.array_equal(hashes, ohash)
+    assert counts[0, 2] == n and counts[0, 0] == int((ores == 0).sum()) and counts[0, 1] == int((ores == -1).sum())
+    st = eng.stats()
+    assert st["capacity_faults"] == 0
+
+
+def test_rollout_schedule_two_weight_vectors(engines):
+    """Different individuals on each side, mixed decks: per-individual counters equal the oracle's."""
+    from oracle_rollout import oracle_rollout_fn
+    rs = np.random.RandomState(3)
+    weights = rs.uniform(0, 1, (6, 10))
+    decks = np.stack([np.stack([deck_indices("N12M"), deck_indices("N12V")]), np.stack([deck_indices("IRONCLAD"), deck_indices("SWARM")])])
+    m = np.zeros(96, dtype=[("p1", "<i4"), ("p2", "<i4"), ("seed", "<u4"), ("deck", "<u4")])
+    m["p1"] = rs.randint(0, 6, 96)
+    m["p2"] = rs.randint(0, 6, 96)
+    m["seed"] = rs.randint(0, 2**31, 96)
+    m["deck"] = rs.randint(0, 2, 96)
+    eng = engines(64)   # capacity < matches: exercises the batching loop
+    counts, results, steps = eng.rollout(weights, m, decks, 120, want_results=True)
+    ocounts, ores, osteps = oracle_rollout_fn(weights, m, decks, 120, want_results=True)
+    assert np.array_equal(results, ores) and np.array_equal(steps, osteps)
+    assert np.array_equal(counts, ocounts)
+
+
+def test_full_size_65536_games_bit_exact_and_deterministic(engines):
+    """BASELINE configs[1]: 65 536 concurrent N12M self-play games, 200 decision rounds; every
+    final canonical record and per-game decision count equals the CPU replay; a second run of the
+    same batch reproduces the same bytes."""
+    n = 65536
+    deck = deck_indices("N12M")
+    eng = engines(n)
+    seeds = np.arange(n, dtype=np.uint32)
+
+    def run():
+        eng.reset(seeds, np.stack([deck, deck]))
+        eng.upload_weights(W0[None])
+        eng.assign_players(np.zeros(n, dtype=np.int32), np.zeros(n, dtype=np.int32))
+        m = np.zeros(n, dtype=[("p1", "<i4"), ("p2", "<i4"), ("seed", "<u4"), ("deck", "<u4")])
+        m["seed"] = seeds
+        _, results, steps = eng.rollout(W0[None], m, np.stack([deck, deck])[None], 200, want_results=True)
+        return results, steps, eng.state_hash()
+    r1, s1, h1 = run()
+    r2, s2, h2 = run()
+    assert np.array_equal(h1, h2) and np.array_equal(r1, r2) and np.array_equal(s1, s2)
+    orc = oracle_lib.Oracle(n)
+    for i in range(n):
+        orc.reset(i, i, deck, deck)
+    _, ores, osteps, ohash = orc.rollout_batch(n, W0, 200, 16)
+    assert np.array_equal(r1, ores)
+    assert np.array_equal(s1, osteps)
+    assert np.array_equal(h1, ohash)
+    assert eng.stats()["capacity_faults"] == 0
+
+
+def test_game_view_and_error_behaviour(engines):
+    from monsoon_amd import MonsoonError
+    from monsoon_amd.engine import BatchEngine
+    from monsoon_amd.game import Game
+    g = Game(0)
+    orc = oracle_lib.Oracle(1)
+    orc.reset(0, 0, deck_indices("IRONCLAD"), deck_indices("SWARM"), 3, 2)
+    assert g.legal_actions() == orc.legal_actions(0) == [0, 1, 2, 3, 16, 17, 18, 19, 32, 33, 34, 35, 148, 149, 150, 151]
+    obs0 = g.reset()
+    assert obs0.shape == (27, 5, 4) and obs0.dtype == np.int32 and np.array_equal(obs0, orc.observe(0))
+    obs, reward, done = g.step(0)
+    orc.step(0, 0)
+    assert np.array_equal(obs, orc.observe(0)) and reward in (0, 10) and done is False
+    assert g.to_play() == 0
+    with pytest.raises(MonsoonError, match="illegal action"):
+        g.step(64)   # no spell in hand slot 0
+    g.close()
+    e = BatchEngine(4)
+    with pytest.raises(MonsoonError, match="monsoon_reset first"):
+        e.legal_mask()
+    bad = np.stack([deck_indices("S12"), deck_indices("S12")])
+    with pytest.raises(MonsoonError, match="not supported"):
+        e.reset(np.array([1], dtype=np.uint32), bad[None])
+    e.close()

@@ -1,0 +1,105 @@
+"""CPU tests of the host side that stays Python: config, GA operators, schedules, Seam F."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from monsoon_amd.config import EvolutionaryConfig
+from monsoon_amd.evolution import EvolutionEngine
+from monsoon_amd.fitness import (FitnessEvaluator, fitness_from_counts, hash32, ring_schedule, round_robin_schedule,
+                                 shard_by_individual)
+from monsoon_amd.population import Population
+from monsoon_amd.weights import WeightVector
+from oracle_rollout import oracle_rollout_fn
+
+
+def test_config_validation_and_json(tmp_path):
+    with pytest.raises(ValueError):
+        EvolutionaryConfig(mu=0)
+    with pytest.raises(ValueError):
+        EvolutionaryConfig(tau=-1)
+    nested = {"population": {"mu": 4, "lambda_": 6}, "evolution": {"generations": 3},
+              "evaluation": {"games_per_pairing": 2, "deck_configs": 1},
+              "simulation": {"max_turns": 50, "num_workers": 2, "timeout_seconds": 5}}
+    p = tmp_path / "c.json"
+    p.write_text(json.dumps(nested))
+    c = EvolutionaryConfig.from_json(str(p))
+    assert (c.mu, c.lambda_, c.generations, c.games_per_pairing, c.max_turns) == (4, 6, 3, 2, 50)
+    assert EvolutionaryConfig.from_dict(c.to_dict()).to_dict() == c.to_dict()
+
+
+def test_population_matches_reference_numerics(gold):
+    """Same numpy global-stream call order as evo/population.py: seed 42 gives the reference's
+    initial population and first offspring (fixture generated from the reference)."""
+    g = gold("population_seed42.npz")
+    pop = Population(EvolutionaryConfig(mu=12, lambda_=12, seed=42))
+    pop.initialize_population(10)
+    assert np.array_equal(np.array([i.get_weights() for i in pop.individuals]), g["init_weights"])
+    assert np.array_equal(np.array([i.get_sigmas() for i in pop.individuals]), g["init_sigmas"])
+    off = pop.generate_offspring()
+    assert np.array_equal(np.array([i.get_weights() for i in off]), g["off_weights"])
+    assert np.array_equal(np.array([i.get_sigmas() for i in off]), g["off_sigmas"])
+
+
+def test_weight_vector_bounds():
+    np.random.seed(0)
+    w = WeightVector(10)
+    for _ in range(50):
+        w.mutate(0.5, 0.5, 1e-5)
+        assert (w.weights >= 0).all() and (w.weights <= 1).all() and (w.sigmas >= 1e-5).all()
+    c = w.copy()
+    assert np.array_equal(c.weights, w.weights) and c.weights is not w.weights
+
+
+def test_schedules():
+    m = round_robin_schedule(3, 5, 2, generation=7)
+    assert len(m) == 3 * 4 * 2
+    assert not np.any((m["p1"] == m["p2"]))
+    assert set(m["p2"]) == {0, 1, 2, 3, 4} and set(m["p1"]) == {0, 1, 2}
+    assert len(set(m["seed"])) == len(m)
+    r = ring_schedule(8, 3, generation=0)
+    assert len(r) == 24 and all(r["p2"][i] == (r["p1"][i] + 1 + i % 3) % 8 for i in range(24))
+    parts = [shard_by_individual(r, 8, k, 3) for k in range(3)]
+    assert sum(len(p) for p in parts) == len(r)
+    assert hash32(1, 2, 3) == hash32(1, 2, 3) != hash32(3, 2, 1)
+    assert fitness_from_counts(np.array([[3, 2, 8]]), 8) == [0.5]
+
+
+def test_as_written_mode_reproduces_reference_logs():
+    """The reference's fitness loop never plays a game: every individual scores exactly 1.0
+    (results/evolutionary2/training_log.csv: best = mean = 1.0, std = 0)."""
+    np.random.seed(1)
+    cfg = EvolutionaryConfig(mu=4, lambda_=4, games_per_pairing=3, mode="as_written")
+    ev = FitnessEvaluator(cfg)
+    pop = [WeightVector(10) for _ in range(4)]
+    assert ev.evaluate_population(pop, 0) == [1.0] * 4
+    assert len(ev.hall_of_fame) == 4
+    assert ev.evaluate_population(pop, 1) == [1.0] * 4      # now with hall-of-fame opponents
+    assert ev.get_stats()["total_games"] == 4 * 3 * 3 + 4 * 7 * 3
+
+
+def test_evaluator_rollout_mode_with_oracle_backend():
+    np.random.seed(2)
+    cfg = EvolutionaryConfig(mu=3, lambda_=3, games_per_pairing=1, max_turns=12)
+    ev = FitnessEvaluator(cfg, rollout_fn=oracle_rollout_fn)
+    pop = [WeightVector(10) for _ in range(3)]
+    f = ev.evaluate_population(pop, 0)
+    assert len(f) == 3 and all(0.0 <= x <= 1.0 for x in f)
+    # 12 decisions cannot finish an N12M game: all draws -> 0.5
+    assert f == [0.5, 0.5, 0.5]
+
+
+def test_evolution_engine_end_to_end(tmp_path):
+    cfg = EvolutionaryConfig(mu=3, lambda_=3, generations=2, games_per_pairing=1, max_turns=6, seed=5,
+                             checkpoint_interval=1, results_dir=str(tmp_path / "res"))
+    eng = EvolutionEngine(cfg, rollout_fn=oracle_rollout_fn)
+    eng.initialize()
+    res = eng.run()
+    assert res["generations"] == 2
+    log = open(os.path.join(cfg.results_dir, "training_log.csv")).read().splitlines()
+    assert log[0].startswith("generation,time,best_fitness") and len(log) == 3
+    assert os.path.exists(res["final_population_file"])
+    eng2 = EvolutionEngine(cfg, rollout_fn=oracle_rollout_fn)
+    eng2.load_checkpoint(res["final_population_file"])
+    assert eng2.population.generation == 2
