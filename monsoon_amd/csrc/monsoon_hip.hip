@@ -617,7 +617,7 @@ int monsoon_create(const monsoon_config* cfg, monsoon_t** out) {
   monsoon* h = new monsoon();
   memset(&h->b, 0, sizeof(h->b));
   h->cfg = *cfg;
-  if (h->cfg.lanes_per_game != 16 && h->cfg.lanes_per_game != 32 && h->cfg.lanes_per_game != 64) h->cfg.lanes_per_game = 32;
+  if (h->cfg.lanes_per_game != 16 && h->cfg.lanes_per_game != 32 && h->cfg.lanes_per_game != 64) h->cfg.lanes_per_game = 16;
   if (h->cfg.stack_bytes <= 0) h->cfg.stack_bytes = 16384;
   h->device = cfg->device;
   h->n = 0;
@@ -847,9 +847,9 @@ static int launch_decide(monsoon_t* h, int n, int max_turns, int write_scores, b
     HIP_TRY(h, hipEventRecord(e0, h->stream));
   }
   switch (h->cfg.lanes_per_game) {
-    case 16: hipLaunchKernelGGL(k_decide<16>, dim3(n), dim3(64), 0, h->stream, h->b, n, max_turns, write_scores); break;
+    default: hipLaunchKernelGGL(k_decide<16>, dim3(n), dim3(64), 0, h->stream, h->b, n, max_turns, write_scores); break;
     case 64: hipLaunchKernelGGL(k_decide<64>, dim3(n), dim3(64), 0, h->stream, h->b, n, max_turns, write_scores); break;
-    default: hipLaunchKernelGGL(k_decide<32>, dim3(n), dim3(64), 0, h->stream, h->b, n, max_turns, write_scores); break;
+    case 32: hipLaunchKernelGGL(k_decide<32>, dim3(n), dim3(64), 0, h->stream, h->b, n, max_turns, write_scores); break;
   }
   HIP_TRY(h, hipGetLastError());
   if (timed) {

@@ -128,6 +128,8 @@ class BatchEngine:
         steps = np.zeros(len(m), dtype=np.int32) if want_results else None
         self._ck(self.lib.monsoon_rollout(self.h, _ptr(weights), n_ind, _ptr(m), len(m), _ptr(deck_pairs), len(deck_pairs),
                                           max_turns, _ptr(counts), _ptr(results), _ptr(steps)), "monsoon_rollout")
+        # the handle now holds the last batch of the schedule
+        self.n = len(m) - ((len(m) - 1) // self.max_games) * self.max_games
         return (counts, results, steps) if want_results else counts
 
     # ---- device-resident rounds (bench) -------------------------------------------------------
