@@ -36,12 +36,22 @@ HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 BYTES_LOOKAHEAD, BYTES_COMMIT = 904, 1736
 
 
-def cpu_baseline(sample_games, max_turns):
+def recorded_traffic():
+    """HBM bytes per k_decide launch from the committed rocprofv3 PMC passes (profiles/traffic.json,
+    written by scripts/summarize_profile.py); None if no profile has been recorded."""
+    p = os.path.join(REPO, "profiles", "traffic.json")
+    if os.path.exists(p):
+        return json.load(open(p)).get("bytes_per_launch")
+    return None
+
+
+def cpu_baseline(sample_games, max_turns, threads):
     """The CPU replay oracle (oracle/, kind 'port') timed on the host cores: a bounded sample of the
     same workload (same deck, weights, seeds 0..sample-1, same step accounting)."""
     sys.path.insert(0, os.path.join(REPO, "tests"))
     import oracle_lib
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cores = max(1, min(avail, threads))   # a one-GPU box's CPU share is 16 cores
     deck = deck_indices("N12M")
     orc = oracle_lib.Oracle(sample_games)
     for i in range(sample_games):
@@ -63,6 +73,7 @@ def main():
     ap.add_argument("--lanes", type=int, default=0)
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=8192)
+    ap.add_argument("--cpu-threads", type=int, default=16)
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -145,12 +156,12 @@ def main():
             "lookahead_per_decision": tot_look / max(tot_dec, 1),
             "faults": st["faults"], "capacity_faults": st["capacity_faults"],
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": recorded_traffic(),
                          "kernel": "k_decide", "avg_launch_ms": 1000.0 * avg_launch_s, "launches": launches,
                          "algorithmic_bytes_per_launch": alg_bytes},
         }
-        if not args.no_cpu and world == 1 or (not args.no_cpu and rank == 0):
-            line["cpu_baseline"] = cpu_baseline(args.cpu_sample, 200)
+        if not args.no_cpu and world == 1:
+            line["cpu_baseline"] = cpu_baseline(args.cpu_sample, 200, args.cpu_threads)
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.barrier()

@@ -1,0 +1,16 @@
+#!/bin/bash
+# Round-1 profile recipe (run on the GPU box via gpurun from the repo root).
+# Kernel trace + stats and the two HBM counters in SEPARATE passes (MI355X_MICROARCH.md: FETCH_SIZE
+# takes 3 TCC slots, WRITE_SIZE 2; gpurun refuses --pmc combined with trace domains other than
+# kernel-trace).
+set -e
+ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$ROOT/gpurun_out/prof_$1
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+ARGS="--steps 40 --warmup 20 --no-cpu"
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $ROOT/bench.py $ARGS > $OUT/bench_trace.json 2> $OUT/trace.err
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 $ROOT/bench.py $ARGS > $OUT/bench_fetch.json 2> $OUT/fetch.err
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 $ROOT/bench.py $ARGS > $OUT/bench_write.json 2> $OUT/write.err
+rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_LDS --output-format csv -d $OUT/pmc_sq -- python3 $ROOT/bench.py $ARGS > $OUT/bench_sq.json 2> $OUT/sq.err || true
+find $OUT -name "*.csv" | head -40
