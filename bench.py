@@ -150,7 +150,7 @@ def main():
             "dtype": "u8/i16 state, f64 draw+score",
             "data": "synthetic",
             "config": {"workload": "C2: 65536 N12M-vs-N12M heuristic self-play games per GPU, W0 both sides, one decision "
-                                   "round per step", "games_per_gpu": n, "lanes_per_game": args.lanes or 16,
+                                   "round per step", "games_per_gpu": n, "lanes_per_game": args.lanes or 8,
                        "parallelism": f"games sharded x{world}, no data-path collective"},
             "decisions_per_s": tot_dec / max_dt,
             "lookahead_per_decision": tot_look / max(tot_dec, 1),

@@ -36,7 +36,7 @@ typedef struct monsoon monsoon_t;
 typedef struct {
   int32_t device;          /* HIP device ordinal */
   int32_t max_games;       /* capacity of the batch */
-  int32_t lanes_per_game;  /* candidate successor states resident per wavefront: 16, 32 or 64 (0 = default) */
+  int32_t lanes_per_game;  /* candidate successor states resident per wavefront: 8, 16, 32 or 64 (0 = default 8) */
   int32_t stack_bytes;     /* per-lane scratch stack for the rules core's recursion (0 = default) */
 } monsoon_config;
 

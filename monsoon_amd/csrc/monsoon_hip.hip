@@ -8,8 +8,9 @@
 //     word-interleaved across lanes (word w of lane l at w*U+l), so lanes touching the same field
 //     hit distinct LDS banks.  Scores are reduced with 64-lane shuffles (first maximum in
 //     ascending action order = np.argmax over the sorted legal list) and the winner's column is
-//     written back as the game's new record.  No look-ahead is re-executed when the legal set
-//     fits in U lanes (the committed successor IS one of the look-ahead results).
+//     written back as the game's new record.  Nothing is re-executed: the committed successor IS
+//     one of the look-ahead results (when the legal set needs several passes of U lanes, the best
+//     successor so far is parked in a spare LDS column).
 //   * The game's MT19937 stream lives in HBM as two blocks of tempered outputs (current + next)
 //     plus the raw state; candidate steps read it through a private cursor, the committed
 //     cursor is stored back and the wave regenerates a block (twist in LDS) when it is used up.
@@ -22,6 +23,7 @@
 
 #include <math.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <string>
@@ -326,12 +328,12 @@ __device__ MSB_INL int nth_set_bit(const uint64_t mask[3], int k) {
   return -1;
 }
 
-template <int U>
-__global__ void __launch_bounds__(64) k_decide(DevBuffers b, int n, int max_turns, int write_scores) {
-  constexpr int PRIV_WORDS = SW * U;
-  static_assert(PRIV_WORDS >= MT_N, "private region doubles as the twist buffer");
+template <int U, int WPE>
+__global__ void __launch_bounds__(64, WPE) k_decide(DevBuffers b, int n, int max_turns, int write_scores) {
+  constexpr int PRIV_WORDS = SW * U > MT_N ? SW * U : MT_N;   // the private region doubles as the twist buffer
   __shared__ uint32_t s_par[SW];
   __shared__ uint32_t s_priv[PRIV_WORDS];
+  __shared__ uint32_t s_best[SW];
   const int g = blockIdx.x;
   const int lane = threadIdx.x;
   if (g >= n) return;
@@ -382,19 +384,28 @@ __global__ void __launch_bounds__(64) k_decide(DevBuffers b, int n, int max_turn
   Engine<LdsMem> ce;
   ce.m.base = priv + lane;
   ce.m.stride = U;
-  double best_s = 0.0;
-  int best_a = 1 << 20;
-  uint32_t my_pos = 0;
-  int my_fault = 0;
+  // Running best over the passes (uniform across the wave).  When the legal set needs more than
+  // one pass, the best successor so far is parked in a spare LDS column so that nothing is replayed.
+  constexpr int NONE_A = 1 << 20;
+  double run_s = 0.0;
+  int run_a = NONE_A;
+  uint32_t new_pos = 0;
+  int cfault = 0;
+  int wl = 0;                       // column (lane) holding the committed successor
+  const bool multi = n_legal > U;
+  MSB_AS_LDS uint32_t* bestcol = (MSB_AS_LDS uint32_t*)s_best;
   for (int base = 0; base < n_legal; base += U) {
     int k = base + lane;
+    double s = 0.0;   // except Exception -> 0.0 (evo/heuristic_agent.py:48-51)
+    int a = NONE_A;
+    uint32_t my_pos = 0;
+    int my_fault = 0;
     if (lane < U && k < n_legal) {
-      int a = nth_set_bit(mask, k);
+      a = nth_set_bit(mask, k);
       for (int i = 0; i < STATE_WORDS; i++) priv[i * U + lane] = par[i];
       ce.rng = pe.rng;
       int r, d;
       ce.step(a, &r, &d);
-      double s = 0.0;   // except Exception -> 0.0 (evo/heuristic_agent.py:48-51)
       int f = ce.fault();
       bool raises = f == 0 && ce.observation_raises();
       if (f == 0 && !before_raises && !raises) {
@@ -403,52 +414,44 @@ __global__ void __launch_bounds__(64) k_decide(DevBuffers b, int n, int max_turn
         s = Engine<LdsMem>::action_score(w, fb, fa);
       }
       if (write_scores) b.scores[(size_t)g * MONSOON_NUM_ACTIONS + a] = s;
-      if (best_a == (1 << 20) || s > best_s) {
-        best_s = s;
-        best_a = a;
-        my_pos = ce.rng.pos;
-        my_fault = f ? f : (raises ? FAULT_INT_CARD : 0);
+      my_pos = ce.rng.pos;
+      my_fault = f ? f : (raises ? FAULT_INT_CARD : 0);
+    }
+    // first maximum over the ascending legal list == (max score, then min action id)
+    double cs = s;
+    int ca = a;
+    for (int off = 32; off >= 1; off >>= 1) {
+      double os = __shfl_xor(cs, off);
+      int oa = __shfl_xor(ca, off);
+      bool take = (oa != NONE_A) && (ca == NONE_A || os > cs || (os == cs && oa < ca));
+      if (take) {
+        cs = os;
+        ca = oa;
+      }
+    }
+    if (ca != NONE_A && (run_a == NONE_A || cs > run_s)) {   // later passes hold larger action ids: strict >
+      run_s = cs;
+      run_a = ca;
+      unsigned long long bal = __ballot(a == ca);
+      wl = __ffsll((long long)bal) - 1;
+      new_pos = __shfl(my_pos, wl);
+      cfault = __shfl(my_fault, wl);
+      if (multi) {
+        __syncthreads();
+        for (int i = lane; i < STATE_WORDS; i += 64) bestcol[i] = priv[i * U + wl];
+        __syncthreads();
       }
     }
   }
-  // first maximum over the ascending legal list == (max score, then min action id)
-  double rs = best_s;
-  int ra = best_a;
-  for (int off = 32; off >= 1; off >>= 1) {
-    double os = __shfl_xor(rs, off);
-    int oa = __shfl_xor(ra, off);
-    bool take = (oa != (1 << 20)) && (ra == (1 << 20) || os > rs || (os == rs && oa < ra));
-    if (take) {
-      rs = os;
-      ra = oa;
-    }
-  }
-  const int A = ra;
-  int wl;   // lane whose column holds the committed successor
-  uint32_t new_pos;
-  int cfault;
-  if (n_legal <= U) {
-    unsigned long long bal = __ballot(best_a == A);
-    wl = __ffsll((long long)bal) - 1;
-    new_pos = __shfl(my_pos, wl);
-    cfault = __shfl(my_fault, wl);
-  } else {
-    // the legal set did not fit in one pass: replay the chosen action once on lane 0
-    wl = 0;
-    if (lane == 0) {
-      for (int i = 0; i < STATE_WORDS; i++) priv[i * U] = par[i];
-      ce.rng = pe.rng;
-      int r, d;
-      ce.step(A, &r, &d);
-      my_pos = ce.rng.pos;
-      my_fault = ce.fault() ? ce.fault() : (ce.observation_raises() ? FAULT_INT_CARD : 0);
-    }
-    new_pos = __shfl(my_pos, 0);
-    cfault = __shfl(my_fault, 0);
-  }
+  const int A = run_a;
+  const double rs = run_s;
   __syncthreads();
   // commit: adapter = adapter.apply_action(best)
-  for (int i = lane; i < STATE_WORDS; i += 64) grec[i] = priv[i * U + wl];
+  if (multi) {
+    for (int i = lane; i < STATE_WORDS; i += 64) grec[i] = bestcol[i];
+  } else {
+    for (int i = lane; i < STATE_WORDS; i += 64) grec[i] = priv[i * U + wl];
+  }
   __syncthreads();
   int cur = (meta.rng >> 16) & 1;
   if (new_pos >= (uint32_t)MT_N) {
@@ -460,7 +463,7 @@ __global__ void __launch_bounds__(64) k_decide(DevBuffers b, int n, int max_turn
     meta.rng = new_pos | ((uint32_t)cur << 16);
     meta.steps++;
     meta.last_action = (uint8_t)A;
-    int executed = n_legal + (n_legal > U ? 1 : 0);
+    int executed = n_legal;   // every legal action is stepped exactly once; the commit re-executes nothing
     meta.lookahead += (uint32_t)executed;
     atomicAdd(&b.stats[ST_LOOKAHEAD], (unsigned long long)executed);
     atomicAdd(&b.stats[ST_DECISIONS], 1ull);
@@ -524,6 +527,7 @@ struct monsoon {
   int device;
   hipStream_t stream;
   DevBuffers b;
+  int wpe;            // k_decide variant: __launch_bounds__ waves per SIMD
   int n;              // games loaded by the last reset
   int n_individuals;
   std::string err;
@@ -617,7 +621,10 @@ int monsoon_create(const monsoon_config* cfg, monsoon_t** out) {
   monsoon* h = new monsoon();
   memset(&h->b, 0, sizeof(h->b));
   h->cfg = *cfg;
-  if (h->cfg.lanes_per_game != 16 && h->cfg.lanes_per_game != 32 && h->cfg.lanes_per_game != 64) h->cfg.lanes_per_game = 16;
+  if (h->cfg.lanes_per_game != 8 && h->cfg.lanes_per_game != 16 && h->cfg.lanes_per_game != 32 && h->cfg.lanes_per_game != 64)
+    h->cfg.lanes_per_game = 8;
+  h->wpe = h->cfg.lanes_per_game == 8 ? 4 : 2;
+  if (const char* e = getenv("MONSOON_WPE")) h->wpe = atoi(e);   // tuning knob: min waves per SIMD the kernel is built for
   if (h->cfg.stack_bytes <= 0) h->cfg.stack_bytes = 16384;
   h->device = cfg->device;
   h->n = 0;
@@ -846,11 +853,22 @@ static int launch_decide(monsoon_t* h, int n, int max_turns, int write_scores, b
     HIP_TRY(h, hipEventCreate(&e1));
     HIP_TRY(h, hipEventRecord(e0, h->stream));
   }
-  switch (h->cfg.lanes_per_game) {
-    default: hipLaunchKernelGGL(k_decide<16>, dim3(n), dim3(64), 0, h->stream, h->b, n, max_turns, write_scores); break;
-    case 64: hipLaunchKernelGGL(k_decide<64>, dim3(n), dim3(64), 0, h->stream, h->b, n, max_turns, write_scores); break;
-    case 32: hipLaunchKernelGGL(k_decide<32>, dim3(n), dim3(64), 0, h->stream, h->b, n, max_turns, write_scores); break;
+#define MSB_LAUNCH(U, W) hipLaunchKernelGGL((k_decide<U, W>), dim3(n), dim3(64), 0, h->stream, h->b, n, max_turns, write_scores)
+  int variant = h->cfg.lanes_per_game * 10 + h->wpe;
+  switch (variant) {
+    case 81: MSB_LAUNCH(8, 1); break;
+    case 82: MSB_LAUNCH(8, 2); break;
+    case 83: MSB_LAUNCH(8, 3); break;
+    case 161: MSB_LAUNCH(16, 1); break;
+    case 163: MSB_LAUNCH(16, 3); break;
+    case 164: MSB_LAUNCH(16, 4); break;
+    case 321: MSB_LAUNCH(32, 1); break;
+    case 322: MSB_LAUNCH(32, 2); break;
+    case 641: MSB_LAUNCH(64, 1); break;
+    case 162: MSB_LAUNCH(16, 2); break;
+    default: MSB_LAUNCH(8, 4); break;
   }
+#undef MSB_LAUNCH
   HIP_TRY(h, hipGetLastError());
   if (timed) {
     HIP_TRY(h, hipEventRecord(e1, h->stream));
