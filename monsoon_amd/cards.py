@@ -17,7 +17,7 @@ CARD_IDS = [c["id"] for c in CARD_META]
 CARD_INDEX = {cid: i for i, cid in enumerate(CARD_IDS)}
 
 # Abilities not restated yet by this build (monsoon_amd/csrc/abilities.inc header).
-UNSUPPORTED = frozenset({"u017", "ua20", "b005", "b006", "b305", "s203"})
+UNSUPPORTED = frozenset({"ua20", "b005"})
 # int(card) raises for these (card.py:46): every observation containing one faults.
 FAULT_CARDS = frozenset({"up01", "up02", "up03"})
 

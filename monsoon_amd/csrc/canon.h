@@ -41,12 +41,12 @@ MSB_HD inline int canon_record(const Engine<M>& g, uint32_t next_u32, uint8_t* o
     for (int i = 0; i < g.pl_hand_n(o); i++) {
       p8(g.hand_card(o, i));
       p8(g.hand_cost(o, i));
-      p8(g.hand_flags(o, i));
+      p8(g.hand_flags(o, i) & (CF_SINGLE_USE | CF_FF));
     }
     for (int i = 0; i < g.pl_deck_n(o); i++) {
       p8(g.deck_card(o, i));
       p8(g.deck_cost(o, i));
-      p8(g.deck_flags(o, i));
+      p8(g.deck_flags(o, i) & (CF_SINGLE_USE | CF_FF));
       union { double d; uint8_t b[8]; } u;
       u.d = g.deck_w(o, i);
       for (int k = 0; k < 8; k++) p8(u.b[k]);

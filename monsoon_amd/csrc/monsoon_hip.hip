@@ -567,7 +567,7 @@ static const char* kCardIds[NUM_CARDS] = {
 
 // Cards whose abilities this build does not restate yet (abilities.inc header).
 static bool card_unsupported(int c) {
-  return c == C_U017 || c == C_UA20 || c == C_B005 || c == C_B006 || c == C_B305 || c == C_S203;
+  return c == C_UA20 || c == C_B005;
 }
 
 extern "C" {

@@ -12,6 +12,7 @@
 // scratch stack); only the tail call at the end of the ability wrapper (card.py:54-60) is a loop.
 #pragma once
 #include "mt19937.h"
+#include "pyset.h"
 #include "state.h"
 
 namespace msb {
@@ -101,6 +102,14 @@ struct Engine {
   MSB_HD MSB_INL int hand_card(int o, int i) const { return m.ld8(pl(o, P_HAND + 4 * i)); }
   MSB_HD MSB_INL int hand_cost(int o, int i) const { return m.ld8(pl(o, P_HAND + 4 * i + 1)); }
   MSB_HD MSB_INL int hand_flags(int o, int i) const { return m.ld8(pl(o, P_HAND + 4 * i + 2)); }
+  MSB_HD MSB_INL int hand_x(int o, int i) const { return m.ld8(pl(o, P_HAND + 4 * i + 3)); }
+  MSB_HD MSB_INL int deck_x(int o, int i) const { return m.ld8(pl(o, P_DECK + 4 * i + 3)); }
+  // strength attribute of a card instance in hand/deck (see CF_ALIAS / CF_STR in state.h)
+  MSB_HD MSB_INL int inst_strength(int card, int fl, int x) const {
+    if (fl & CF_ALIAS) return m.ld16(E_STR + 2 * x);
+    if (fl & CF_STR) return x;
+    return card < NUM_CARDS ? g_cards[card].strength : 0;
+  }
   MSB_HD MSB_INL int deck_card(int o, int i) const { return m.ld8(pl(o, P_DECK + 4 * i)); }
   MSB_HD MSB_INL int deck_cost(int o, int i) const { return m.ld8(pl(o, P_DECK + 4 * i + 1)); }
   MSB_HD MSB_INL int deck_flags(int o, int i) const { return m.ld8(pl(o, P_DECK + 4 * i + 2)); }
@@ -206,6 +215,24 @@ struct Engine {
       if (s != SLOT_NONE) used |= 1u << s;
     }
     m.st32(H_USED, used);
+    // a hand/deck entry aliasing an entity that has left the board keeps that object's last strength
+    for (int o = 0; o < 2; o++) {
+      int hn = pl_hand_n(o), dn = pl_deck_n(o);
+      for (int i = 0; i < hn + dn; i++) {
+        int off = i < hn ? pl(o, P_HAND + 4 * i) : pl(o, P_DECK + 4 * (i - hn));
+        int fl = m.ld8(off + 2);
+        if (!(fl & CF_ALIAS)) continue;
+        int slot = m.ld8(off + 3);
+        if (used & (1u << slot)) continue;
+        int str = e_str(slot);
+        if (str < 0 || str > 255) {
+          set_fault(FAULT_CAPACITY);
+          str = 0;
+        }
+        m.st8(off + 2, (fl & ~CF_ALIAS) | CF_STR);
+        m.st8(off + 3, str);
+      }
+    }
     for (int e = 0; e < NUM_ENT; e++)
       if (!(used & (1u << e))) m.st8(E_CARD + e, CARD_NONE);
     m.st8(H_DEPTH, 0);
@@ -869,6 +896,23 @@ struct Engine {
   // (unit.py:25-26, structure.py:18-19); Spells compare identity (card.py:22-23).
   MSB_HD MSB_INL bool card_eq_by_id(int card) const { return card >= NUM_CARDS || g_cards[card].kind != KIND_SPELL; }
 
+  // list.remove(target): index of the first element EQUAL to the one at `idx`.  Unit/Structure
+  // equality is (card_id, player, position); instances that came back from the board (b305) have a
+  // position, fresh cards have None: comparing None with a Point raises (point.py:6-7).
+  MSB_HD MSB_INL int first_equal(int base_off, int idx) {
+    int card = m.ld8(base_off + 4 * idx);
+    if (!card_eq_by_id(card)) return idx;
+    int positioned = m.ld8(base_off + 4 * idx + 2) & (CF_ALIAS | CF_STR);
+    for (int i = 0; i < idx; i++) {
+      if (m.ld8(base_off + 4 * i) != card) continue;
+      int pi = m.ld8(base_off + 4 * i + 2) & (CF_ALIAS | CF_STR);
+      if (!pi && !positioned) return i;
+      set_fault((pi && positioned) ? FAULT_UNSUPPORTED : FAULT_PY_EXCEPTION);
+      return idx;
+    }
+    return idx;
+  }
+
   // Player.draw, player.py:46-52: numpy choice(deck, size=1, p=w/sum(w))
   MSB_HD MSB_NOINLINE void draw(int o, int amount) {
     for (int k = 0; k < amount; k++) {
@@ -895,25 +939,17 @@ struct Engine {
         set_fault(FAULT_PY_EXCEPTION);
         return;
       }
-      int card = deck_card(o, idx), cost = deck_cost(o, idx), fl = deck_flags(o, idx);
       set_deck_w(o, idx, 1.0);
       int hn = pl_hand_n(o);
       if (hn >= HAND_CAP) {
         set_fault(FAULT_CAPACITY);
         return;
       }
-      m.st8(pl(o, P_HAND + 4 * hn), card);
-      m.st8(pl(o, P_HAND + 4 * hn + 1), cost);
-      m.st8(pl(o, P_HAND + 4 * hn + 2), fl);
+      m.st32(pl(o, P_HAND + 4 * hn), m.ld32(pl(o, P_DECK + 4 * idx)));
       m.st8(pl(o, P_HAND_N), hn + 1);
       // deck.remove(choice): first EQUAL element
-      int j = idx;
-      if (card_eq_by_id(card))
-        for (int i = 0; i < idx; i++)
-          if (deck_card(o, i) == card) {
-            j = i;
-            break;
-          }
+      int j = first_equal(pl(o, P_DECK), idx);
+      if (fault()) return;
       for (int i = j; i + 1 < n; i++) {
         m.st32(pl(o, P_DECK + 4 * i), m.ld32(pl(o, P_DECK + 4 * (i + 1))));
         set_deck_w(o, i, deck_w(o, i + 1));
@@ -930,15 +966,11 @@ struct Engine {
   MSB_HD MSB_NOINLINE void discard(int o, int hand_index) {
     int n = pl_deck_n(o);
     for (int i = 0; i < n; i++) set_deck_w(o, i, deck_w(o, i) * 1.6 + 100);
-    int card = hand_card(o, hand_index), cost = hand_cost(o, hand_index), fl = hand_flags(o, hand_index);
+    uint32_t inst = m.ld32(pl(o, P_HAND + 4 * hand_index));
+    int fl = hand_flags(o, hand_index);
     // hand.remove(target): first equal
-    int j = hand_index;
-    if (card_eq_by_id(card))
-      for (int i = 0; i < hand_index; i++)
-        if (hand_card(o, i) == card) {
-          j = i;
-          break;
-        }
+    int j = first_equal(pl(o, P_HAND), hand_index);
+    if (fault()) return;
     int hn = pl_hand_n(o);
     for (int i = j; i + 1 < hn; i++) m.st32(pl(o, P_HAND + 4 * i), m.ld32(pl(o, P_HAND + 4 * (i + 1))));
     m.st8(pl(o, P_HAND_N), hn - 1);
@@ -947,10 +979,7 @@ struct Engine {
         set_fault(FAULT_CAPACITY);
         return;
       }
-      m.st8(pl(o, P_DECK + 4 * n), card);
-      m.st8(pl(o, P_DECK + 4 * n + 1), cost);
-      m.st8(pl(o, P_DECK + 4 * n + 2), fl);
-      m.st8(pl(o, P_DECK + 4 * n + 3), 0);
+      m.st32(pl(o, P_DECK + 4 * n), inst);
       set_deck_w(o, n, 1.0);  // hand cards always carry weight 1 (player.py:50)
       m.st8(pl(o, P_DECK_N), n + 1);
     }
@@ -974,12 +1003,13 @@ struct Engine {
   // Player.play, player.py:68-77.  has_pos=false <=> position None
   MSB_HD MSB_NOINLINE void player_play(int o, int index, P position, bool has_pos) {
     int card = hand_card(o, index), fl = hand_flags(o, index);
+    int strength = inst_strength(card, fl, hand_x(o, index));   // target.copy() copies the instance's strength
     add_history(o, card);
     discard(o, index);
     if (fault()) return;
     const CardInfo& ci = g_cards[card];
     if (ci.kind == KIND_UNIT) {
-      int e = new_entity(card, o, ci.strength, ci.movement, (fl & CF_FF) != 0);   // target.copy()
+      int e = new_entity(card, o, strength, ci.movement, (fl & CF_FF) != 0);   // target.copy()
       if (fault()) return;
       if (!has_pos) {
         set_fault(FAULT_PY_EXCEPTION);
@@ -987,8 +1017,9 @@ struct Engine {
       }
       unit_play(e, position);
     } else if (ci.kind == KIND_STRUCT) {
-      int e = new_entity(card, o, ci.strength, 0, false);
+      int e = new_entity(card, o, strength, 0, false);
       if (fault()) return;
+      if (fl & CF_SINGLE_USE) e_set_flag(e, EF_SINGLE_USE, true);
       if (!has_pos) {
         set_fault(FAULT_PY_EXCEPTION);
         return;

@@ -57,7 +57,11 @@ constexpr int P_DECK = P_HAND + 4 * HAND_CAP;   // DECK_CAP x {card, cost, flags
 constexpr int P_WEIGHT = (P_DECK + 4 * DECK_CAP + 7) & ~7;  // DECK_CAP x f64
 constexpr int PL_SIZE = P_WEIGHT + 8 * DECK_CAP;
 static_assert((OFF_PL % 8) == 0 && (PL_SIZE % 8) == 0, "f64 alignment");
-constexpr int CF_SINGLE_USE = 1, CF_FF = 2;     // card-instance flags (hand/deck entries)
+// card-instance flags (hand/deck entries {card, cost, flags, x}).  b305 puts the on-board structure OBJECT
+// back into the hand (cards/b305.py:40-45): such an entry aliases entity slot x while that entity is
+// on the board (CF_ALIAS) and keeps its last strength in x afterwards (CF_STR).  Both kinds have a
+// position attribute, which matters for list.remove's equality (structure.py:18-19).
+constexpr int CF_SINGLE_USE = 1, CF_FF = 2, CF_STR = 4, CF_ALIAS = 8;
 
 // ---- entities (field arrays) ------------------------------------------------------------------
 constexpr int OFF_ENT = OFF_PL + 2 * PL_SIZE;
@@ -73,7 +77,7 @@ constexpr int E_DMG = E_STR + 2 * NUM_ENT;      // i16 damage_taken
 constexpr int E_PATH = (E_DMG + 2 * NUM_ENT + 3) & ~3;  // u32 packed path (PATH_CAP bytes)
 constexpr int STATE_BYTES = (E_PATH + 4 * NUM_ENT + 7) & ~7;
 constexpr int STATE_WORDS = STATE_BYTES / 4;
-constexpr int EF_OWNER = 1, EF_FF = 2, EF_RESOLVING_PLAY = 4;
+constexpr int EF_OWNER = 1, EF_FF = 2, EF_RESOLVING_PLAY = 4, EF_SINGLE_USE = 8;
 
 // ---- accessors ----------------------------------------------------------------------------------
 // Host / flat: the record is a contiguous byte array.

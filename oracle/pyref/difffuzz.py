@@ -28,7 +28,7 @@ for name in ("orc_reset", "orc_legal", "orc_step", "orc_observe", "orc_features"
              "orc_canon_hash", "orc_have_winner", "orc_to_play", "orc_decide"):
     getattr(LIB, name).argtypes = None
 
-UNSUPPORTED = {"u017", "ua20", "b005", "b006", "b305", "s203"}
+UNSUPPORTED = {"ua20", "b005"}
 FAULT_CARDS = {"up01", "up02", "up03"}
 
 
@@ -132,6 +132,7 @@ def main():
     ap.add_argument("--games", type=int, default=20)
     ap.add_argument("--steps", type=int, default=400)
     ap.add_argument("--seed0", type=int, default=0)
+    ap.add_argument("--must", default="", help="comma list of card ids forced into both random decks (with --pool)")
     args = ap.parse_args()
     total, bad = 0, 0
     pool = None
@@ -141,8 +142,10 @@ def main():
         seed = args.seed0 + k
         if pool:
             rs = np.random.RandomState(seed ^ 0x9E3779B9)
-            d0 = list(rs.choice(pool, 12, replace=False))
-            d1 = list(rs.choice(pool, 12, replace=False))
+            must = [c for c in args.must.split(",") if c]
+            rest = [c for c in pool if c not in must]
+            d0 = must + list(rs.choice(rest, 12 - len(must), replace=False))
+            d1 = must + list(rs.choice(rest, 12 - len(must), replace=False))
         else:
             d0 = H.DECKS[args.deck]
             d1 = H.DECKS[args.deck2 or args.deck]

@@ -30,7 +30,7 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import harness as H  # noqa: E402
 
 GOLD = os.path.join(H.REPO, "tests", "golden")
-UNSUPPORTED = {"u017", "ua20", "b005", "b006", "b305", "s203"}
+UNSUPPORTED = {"ua20", "b005"}
 FAULT_CARDS = {"up01", "up02", "up03"}
 W0 = np.random.RandomState(2024).uniform(0, 1, 10)
 
