@@ -9,6 +9,8 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmonsoon_hip.so")
+# same source built with -DMSB_EXT=1: larger per-game record, needed by decks holding ua20 or b005
+LIB_PATH_EXT = os.path.join(_HERE, "libmonsoon_hip_ext.so")
 
 OK, ERR_ARG, ERR_DEVICE, ERR_STATE = 0, 1, 2, 3
 NUM_ACTIONS = 156
@@ -33,7 +35,7 @@ class MonsoonError(RuntimeError):
     pass
 
 
-_lib = None
+_libs = {}
 
 # name -> (restype, argtypes); every symbol declared in include/monsoon.h
 SIGNATURES = {
@@ -66,24 +68,24 @@ SIGNATURES = {
 }
 
 
-def load():
+def load(extended=False):
     """Load the HIP library (fails loudly when it has not been built)."""
-    global _lib
-    if _lib is not None:
-        return _lib
-    if not os.path.exists(LIB_PATH):
-        raise MonsoonError(f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
-                           "or `make -C monsoon_amd/csrc` (there is no CPU fallback)")
-    lib = ctypes.CDLL(LIB_PATH)
+    if extended in _libs:
+        return _libs[extended]
+    path = LIB_PATH_EXT if extended else LIB_PATH
+    if not os.path.exists(path):
+        raise MonsoonError(f"{path} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                           "or `make -C monsoon_amd/csrc all` (there is no CPU fallback)")
+    lib = ctypes.CDLL(path)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)   # AttributeError if the ABI and this binding drift apart
         fn.restype = res
         fn.argtypes = args
-    _lib = lib
+    _libs[extended] = lib
     return lib
 
 
-def check(handle, rc, what):
+def check(handle, rc, what, lib=None):
     if rc != OK:
-        msg = load().monsoon_last_error(handle)
+        msg = (lib or load()).monsoon_last_error(handle)
         raise MonsoonError(f"{what} failed (status {rc}): {msg.decode() if msg else ''}")

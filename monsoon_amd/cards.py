@@ -16,8 +16,10 @@ with open(os.path.join(_HERE, "card_ids.json")) as _f:
 CARD_IDS = [c["id"] for c in CARD_META]
 CARD_INDEX = {cid: i for i, cid in enumerate(CARD_IDS)}
 
-# Abilities not restated yet by this build (monsoon_amd/csrc/abilities.inc header).
+# Cards that need the extended per-game record (BatchEngine(extended=True), libmonsoon_hip_ext.so):
+# ua20 grows the deck, b005 keeps deep copies of its neighbours.  The standard build refuses them.
 UNSUPPORTED = frozenset({"ua20", "b005"})
+NEEDS_EXTENDED = UNSUPPORTED
 # int(card) raises for these (card.py:46): every observation containing one faults.
 FAULT_CARDS = frozenset({"up01", "up02", "up03"})
 
@@ -41,5 +43,11 @@ def deck_indices(deck):
     return arr
 
 
-def supported_pool(include_fault_cards=False):
-    return [c for c in CARD_IDS if c not in UNSUPPORTED and (include_fault_cards or c not in FAULT_CARDS)]
+def supported_pool(include_fault_cards=False, extended=False):
+    return [c for c in CARD_IDS if (extended or c not in UNSUPPORTED) and (include_fault_cards or c not in FAULT_CARDS)]
+
+
+def needs_extended(decks):
+    """True if any deck (ids or indices) holds a card that only the extended build supports."""
+    idx = {CARD_INDEX[c] for c in NEEDS_EXTENDED}
+    return any((CARD_INDEX[c] if isinstance(c, str) else int(c)) in idx for c in np.asarray(decks, dtype=object).ravel())

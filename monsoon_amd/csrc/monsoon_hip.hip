@@ -132,15 +132,25 @@ __device__ void lane_commit_rng(const DevBuffers& b, int g, GameMeta& m, const R
 // ------------------------------------------------------------------------------------------------
 // Lane-per-game API kernels.  Block = 64 threads, state staged in LDS word-interleaved.
 // ------------------------------------------------------------------------------------------------
+// games per 64-thread block in the API kernels: the extended record is too large for 64 LDS columns
+#if defined(MSB_EXT) && MSB_EXT
+constexpr int API_LANES = 32;
+#else
+constexpr int API_LANES = 64;
+#endif
 struct ApiLds {
-  uint32_t w[SW * 64];
+  uint32_t w[SW * API_LANES];
 };
+#define API_GAME_INDEX()                                  \
+  if ((int)threadIdx.x >= API_LANES) return;              \
+  int g = blockIdx.x * API_LANES + threadIdx.x;           \
+  if (g >= n) return;
 
 __device__ MSB_INL void api_load(MSB_AS_LDS uint32_t* col, const uint32_t* src) {
-  for (int w = 0; w < STATE_WORDS; w++) col[w * 64] = src[w];
+  for (int w = 0; w < STATE_WORDS; w++) col[w * API_LANES] = src[w];
 }
 __device__ MSB_INL void api_store(uint32_t* dst, MSB_AS_LDS const uint32_t* col) {
-  for (int w = 0; w < STATE_WORDS; w++) dst[w] = col[w * 64];
+  for (int w = 0; w < STATE_WORDS; w++) dst[w] = col[w * API_LANES];
 }
 
 __global__ void __launch_bounds__(64) k_seed(DevBuffers b, int n, const uint32_t* seeds) {
@@ -168,11 +178,10 @@ __global__ void __launch_bounds__(64) k_seed(DevBuffers b, int n, const uint32_t
 
 __global__ void __launch_bounds__(64) k_init(DevBuffers b, int n, const uint8_t* decks, const uint8_t* factions) {
   __shared__ ApiLds lds;
-  int g = blockIdx.x * 64 + threadIdx.x;
-  if (g >= n) return;
+  API_GAME_INDEX();
   Engine<LdsMem> e;
   e.m.base = (MSB_AS_LDS uint32_t*)lds.w + threadIdx.x;
-  e.m.stride = 64;
+  e.m.stride = API_LANES;
   GameMeta m = b.meta[g];
   m.rng = 0;
   e.rng = make_view(b, g, m.rng);
@@ -194,11 +203,10 @@ __global__ void __launch_bounds__(64) k_init(DevBuffers b, int n, const uint8_t*
 
 __global__ void __launch_bounds__(64) k_legal(DevBuffers b, int n, uint64_t* out) {
   __shared__ ApiLds lds;
-  int g = blockIdx.x * 64 + threadIdx.x;
-  if (g >= n) return;
+  API_GAME_INDEX();
   Engine<LdsMem> e;
   e.m.base = (MSB_AS_LDS uint32_t*)lds.w + threadIdx.x;
-  e.m.stride = 64;
+  e.m.stride = API_LANES;
   api_load(e.m.base, b.state + (size_t)g * SW);
   uint64_t mask[3];
   e.legal_mask(mask);
@@ -210,8 +218,7 @@ __global__ void __launch_bounds__(64) k_legal(DevBuffers b, int n, uint64_t* out
 __global__ void __launch_bounds__(64) k_step(DevBuffers b, int n, const uint8_t* actions, int8_t* reward, uint8_t* done,
                                               uint8_t* fault, uint8_t* illegal) {
   __shared__ ApiLds lds;
-  int g = blockIdx.x * 64 + threadIdx.x;
-  if (g >= n) return;
+  API_GAME_INDEX();
   int a = actions[g];
   reward[g] = 0;
   done[g] = 0;
@@ -220,7 +227,7 @@ __global__ void __launch_bounds__(64) k_step(DevBuffers b, int n, const uint8_t*
   if (a == 255) return;
   Engine<LdsMem> e;
   e.m.base = (MSB_AS_LDS uint32_t*)lds.w + threadIdx.x;
-  e.m.stride = 64;
+  e.m.stride = API_LANES;
   api_load(e.m.base, b.state + (size_t)g * SW);
   uint64_t mask[3];
   e.legal_mask(mask);
@@ -245,11 +252,10 @@ __global__ void __launch_bounds__(64) k_step(DevBuffers b, int n, const uint8_t*
 
 __global__ void __launch_bounds__(64) k_observe(DevBuffers b, int n, int32_t* out, uint8_t* raises) {
   __shared__ ApiLds lds;
-  int g = blockIdx.x * 64 + threadIdx.x;
-  if (g >= n) return;
+  API_GAME_INDEX();
   Engine<LdsMem> e;
   e.m.base = (MSB_AS_LDS uint32_t*)lds.w + threadIdx.x;
-  e.m.stride = 64;
+  e.m.stride = API_LANES;
   api_load(e.m.base, b.state + (size_t)g * SW);
   bool r = e.observation_raises();
   raises[g] = r ? 1 : 0;
@@ -258,11 +264,10 @@ __global__ void __launch_bounds__(64) k_observe(DevBuffers b, int n, int32_t* ou
 
 __global__ void __launch_bounds__(64) k_features(DevBuffers b, int n, double* out) {
   __shared__ ApiLds lds;
-  int g = blockIdx.x * 64 + threadIdx.x;
-  if (g >= n) return;
+  API_GAME_INDEX();
   Engine<LdsMem> e;
   e.m.base = (MSB_AS_LDS uint32_t*)lds.w + threadIdx.x;
-  e.m.stride = 64;
+  e.m.stride = API_LANES;
   api_load(e.m.base, b.state + (size_t)g * SW);
   double f[10];
   if (e.observation_raises()) {
@@ -290,7 +295,7 @@ __global__ void __launch_bounds__(64) k_export(DevBuffers b, int g, uint8_t* out
   if (threadIdx.x != 0) return;
   Engine<LdsMem> e;
   e.m.base = (MSB_AS_LDS uint32_t*)lds.w;
-  e.m.stride = 64;
+  e.m.stride = API_LANES;
   api_load(e.m.base, b.state + (size_t)g * SW);
   RngView v = make_view(b, g, b.meta[g].rng);
   uint32_t nx = v.next_u32();
@@ -299,11 +304,10 @@ __global__ void __launch_bounds__(64) k_export(DevBuffers b, int g, uint8_t* out
 
 __global__ void __launch_bounds__(64) k_hash(DevBuffers b, int n, uint64_t* out) {
   __shared__ ApiLds lds;
-  int g = blockIdx.x * 64 + threadIdx.x;
-  if (g >= n) return;
+  API_GAME_INDEX();
   Engine<LdsMem> e;
   e.m.base = (MSB_AS_LDS uint32_t*)lds.w + threadIdx.x;
-  e.m.stride = 64;
+  e.m.stride = API_LANES;
   api_load(e.m.base, b.state + (size_t)g * SW);
   RngView v = make_view(b, g, b.meta[g].rng);
   uint32_t nx = v.next_u32();
@@ -567,12 +571,23 @@ static const char* kCardIds[NUM_CARDS] = {
 
 // Cards whose abilities this build does not restate yet (abilities.inc header).
 static bool card_unsupported(int c) {
-  return c == C_UA20 || c == C_B005;
+#if defined(MSB_EXT) && MSB_EXT
+  (void)c;
+  return false;
+#else
+  return c == C_UA20 || c == C_B005;   // need the extended record: build libmonsoon_hip_ext.so
+#endif
 }
 
 extern "C" {
 
-int monsoon_version(void) { return 1; }
+int monsoon_version(void) {
+#if defined(MSB_EXT) && MSB_EXT
+  return 0x10001;   // bit 16: extended record
+#else
+  return 1;
+#endif
+}
 
 int monsoon_card_index(const char* id) {
   if (!id) return -1;
@@ -675,7 +690,7 @@ static int check_ready(monsoon_t* h) {
 
 static int launch_reset(monsoon_t* h, int n) {
   hipLaunchKernelGGL(k_seed, dim3(n), dim3(64), 0, h->stream, h->b, n, h->d_seeds);
-  hipLaunchKernelGGL(k_init, dim3((n + 63) / 64), dim3(64), 0, h->stream, h->b, n, h->d_decks, h->d_factions);
+  hipLaunchKernelGGL(k_init, dim3((n + API_LANES - 1) / API_LANES), dim3(64), 0, h->stream, h->b, n, h->d_decks, h->d_factions);
   HIP_TRY(h, hipGetLastError());
   return MONSOON_OK;
 }
@@ -712,7 +727,7 @@ int monsoon_legal_mask(monsoon_t* h, uint64_t* out) {
   if (rc) return rc;
   if (!out) return MONSOON_ERR_ARG;
   int n = h->n;
-  hipLaunchKernelGGL(k_legal, dim3((n + 63) / 64), dim3(64), 0, h->stream, h->b, n, h->d_masks);
+  hipLaunchKernelGGL(k_legal, dim3((n + API_LANES - 1) / API_LANES), dim3(64), 0, h->stream, h->b, n, h->d_masks);
   HIP_TRY(h, hipGetLastError());
   HIP_TRY(h, hipMemcpyAsync(out, h->d_masks, (size_t)n * 24, hipMemcpyDeviceToHost, h->stream));
   HIP_TRY(h, hipStreamSynchronize(h->stream));
@@ -726,7 +741,7 @@ int monsoon_step(monsoon_t* h, const uint8_t* actions, int8_t* reward, uint8_t* 
   int n = h->n;
   uint8_t* d = h->d_bytes;   // [actions | reward | done | fault | illegal] x n
   HIP_TRY(h, hipMemcpyAsync(d, actions, n, hipMemcpyHostToDevice, h->stream));
-  hipLaunchKernelGGL(k_step, dim3((n + 63) / 64), dim3(64), 0, h->stream, h->b, n, d, (int8_t*)(d + n), d + 2 * (size_t)n,
+  hipLaunchKernelGGL(k_step, dim3((n + API_LANES - 1) / API_LANES), dim3(64), 0, h->stream, h->b, n, d, (int8_t*)(d + n), d + 2 * (size_t)n,
                      d + 3 * (size_t)n, d + 4 * (size_t)n);
   HIP_TRY(h, hipGetLastError());
   std::vector<uint8_t> host(4 * (size_t)n);
@@ -750,7 +765,7 @@ int monsoon_observe(monsoon_t* h, int32_t* out, uint8_t* raises) {
   if (!out) return MONSOON_ERR_ARG;
   int n = h->n;
   if (!h->d_i32) HIP_TRY(h, hipMalloc(&h->d_i32, (size_t)h->cfg.max_games * MONSOON_OBS_INTS * 4));
-  hipLaunchKernelGGL(k_observe, dim3((n + 63) / 64), dim3(64), 0, h->stream, h->b, n, h->d_i32, h->d_bytes);
+  hipLaunchKernelGGL(k_observe, dim3((n + API_LANES - 1) / API_LANES), dim3(64), 0, h->stream, h->b, n, h->d_i32, h->d_bytes);
   HIP_TRY(h, hipGetLastError());
   HIP_TRY(h, hipMemcpyAsync(out, h->d_i32, (size_t)n * MONSOON_OBS_INTS * 4, hipMemcpyDeviceToHost, h->stream));
   std::vector<uint8_t> r(n);
@@ -766,7 +781,7 @@ int monsoon_features(monsoon_t* h, double* out) {
   if (!out) return MONSOON_ERR_ARG;
   int n = h->n;
   if (!h->d_f64) HIP_TRY(h, hipMalloc(&h->d_f64, (size_t)h->cfg.max_games * 10 * 8));
-  hipLaunchKernelGGL(k_features, dim3((n + 63) / 64), dim3(64), 0, h->stream, h->b, n, h->d_f64);
+  hipLaunchKernelGGL(k_features, dim3((n + API_LANES - 1) / API_LANES), dim3(64), 0, h->stream, h->b, n, h->d_f64);
   HIP_TRY(h, hipGetLastError());
   HIP_TRY(h, hipMemcpyAsync(out, h->d_f64, (size_t)n * 80, hipMemcpyDeviceToHost, h->stream));
   HIP_TRY(h, hipStreamSynchronize(h->stream));
@@ -779,7 +794,7 @@ int monsoon_status(monsoon_t* h, int32_t* out) {
   if (!out) return MONSOON_ERR_ARG;
   int n = h->n;
   if (!h->d_i32) HIP_TRY(h, hipMalloc(&h->d_i32, (size_t)h->cfg.max_games * MONSOON_OBS_INTS * 4));
-  hipLaunchKernelGGL(k_status, dim3((n + 63) / 64), dim3(64), 0, h->stream, h->b, n, h->d_i32);
+  hipLaunchKernelGGL(k_status, dim3((n + API_LANES - 1) / API_LANES), dim3(64), 0, h->stream, h->b, n, h->d_i32);
   HIP_TRY(h, hipGetLastError());
   HIP_TRY(h, hipMemcpyAsync(out, h->d_i32, (size_t)n * 16, hipMemcpyDeviceToHost, h->stream));
   HIP_TRY(h, hipStreamSynchronize(h->stream));
@@ -807,7 +822,7 @@ int monsoon_state_hash(monsoon_t* h, uint64_t* out) {
   if (rc) return rc;
   if (!out) return MONSOON_ERR_ARG;
   int n = h->n;
-  hipLaunchKernelGGL(k_hash, dim3((n + 63) / 64), dim3(64), 0, h->stream, h->b, n, h->d_masks);
+  hipLaunchKernelGGL(k_hash, dim3((n + API_LANES - 1) / API_LANES), dim3(64), 0, h->stream, h->b, n, h->d_masks);
   HIP_TRY(h, hipGetLastError());
   HIP_TRY(h, hipMemcpyAsync(out, h->d_masks, (size_t)n * 8, hipMemcpyDeviceToHost, h->stream));
   HIP_TRY(h, hipStreamSynchronize(h->stream));
@@ -862,9 +877,11 @@ static int launch_decide(monsoon_t* h, int n, int max_turns, int write_scores, b
     case 161: MSB_LAUNCH(16, 1); break;
     case 163: MSB_LAUNCH(16, 3); break;
     case 164: MSB_LAUNCH(16, 4); break;
+#if !(defined(MSB_EXT) && MSB_EXT)
     case 321: MSB_LAUNCH(32, 1); break;
     case 322: MSB_LAUNCH(32, 2); break;
     case 641: MSB_LAUNCH(64, 1); break;
+#endif
     case 162: MSB_LAUNCH(16, 2); break;
     default: MSB_LAUNCH(8, 4); break;
   }

@@ -51,6 +51,11 @@ enum : int {
   FAULT_RNG_OVERRUN = 19,   // one step consumed more than the two resident MT blocks
   FAULT_UNSUPPORTED = 20,   // card ability not implemented yet in this build
   FAULT_STATUS_SAT = 21,    // status multiset count saturated
+  FAULT_CAP_REM = 22,       // b005 snapshot lists
+  FAULT_CAP_DECK = 23,      // deck entries
+  FAULT_CAP_HAND = 24,      // hand entries
+  FAULT_CAP_PATH = 25,      // path longer than PATH_CAP
+  FAULT_CAP_INST = 26,      // card-instance strength outside 0..255
 };
 
 // ---- static card table -----------------------------------------------------------------

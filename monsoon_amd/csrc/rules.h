@@ -99,22 +99,132 @@ struct Engine {
   MSB_HD MSB_INL void set_pl_front(int o, int v) { m.st8(pl(o, P_FRONT), v); }
   MSB_HD MSB_INL int pl_hand_n(int o) const { return m.ld8(pl(o, P_HAND_N)); }
   MSB_HD MSB_INL int pl_deck_n(int o) const { return m.ld8(pl(o, P_DECK_N)); }
-  MSB_HD MSB_INL int hand_card(int o, int i) const { return m.ld8(pl(o, P_HAND + 4 * i)); }
-  MSB_HD MSB_INL int hand_cost(int o, int i) const { return m.ld8(pl(o, P_HAND + 4 * i + 1)); }
-  MSB_HD MSB_INL int hand_flags(int o, int i) const { return m.ld8(pl(o, P_HAND + 4 * i + 2)); }
-  MSB_HD MSB_INL int hand_x(int o, int i) const { return m.ld8(pl(o, P_HAND + 4 * i + 3)); }
-  MSB_HD MSB_INL int deck_x(int o, int i) const { return m.ld8(pl(o, P_DECK + 4 * i + 3)); }
+  // ---- hand / deck lists ---------------------------------------------------------------------
+  // hand_ref/deck_ref: byte offset of the card-instance record {card, cost, flags, x} at a list position;
+  // deck_wref: offset of that card's weight.  Standard record: values stored in place.  Extended record:
+  // positions hold object ids into the player's instance table (state.h).
+#if defined(MSB_EXT) && MSB_EXT
+  MSB_HD MSB_INL int hand_id(int o, int i) const { return m.ld8(pl(o, P_HAND + i)); }
+  MSB_HD MSB_INL int deck_id(int o, int i) const { return m.ld8(pl(o, P_DECK + i)); }
+  MSB_HD MSB_INL int hand_ref(int o, int i) const { return pl(o, P_INST + 4 * hand_id(o, i)); }
+  MSB_HD MSB_INL int deck_ref(int o, int i) const { return pl(o, P_INST + 4 * deck_id(o, i)); }
+  MSB_HD MSB_INL int deck_wref(int o, int i) const { return pl(o, P_WEIGHT + 8 * deck_id(o, i)); }
+  // a free object id: referenced by neither list
+  MSB_HD MSB_NOINLINE int inst_alloc(int o) {
+    uint32_t used = 0;
+    for (int i = 0; i < pl_hand_n(o); i++) used |= 1u << hand_id(o, i);
+    for (int i = 0; i < pl_deck_n(o); i++) used |= 1u << deck_id(o, i);
+    for (int k = 0; k < INST_CAP; k++)
+      if (!(used & (1u << k))) return k;
+    set_fault(FAULT_CAP_DECK);
+    return 0;
+  }
+#else
+  MSB_HD MSB_INL int hand_ref(int o, int i) const { return pl(o, P_HAND + 4 * i); }
+  MSB_HD MSB_INL int deck_ref(int o, int i) const { return pl(o, P_DECK + 4 * i); }
+  MSB_HD MSB_INL int deck_wref(int o, int i) const { return pl(o, P_WEIGHT + 8 * i); }
+#endif
+  MSB_HD MSB_INL int hand_card(int o, int i) const { return m.ld8(hand_ref(o, i)); }
+  MSB_HD MSB_INL int hand_cost(int o, int i) const { return m.ld8(hand_ref(o, i) + 1); }
+  MSB_HD MSB_INL int hand_flags(int o, int i) const { return m.ld8(hand_ref(o, i) + 2); }
+  MSB_HD MSB_INL int hand_x(int o, int i) const { return m.ld8(hand_ref(o, i) + 3); }
+  MSB_HD MSB_INL int deck_card(int o, int i) const { return m.ld8(deck_ref(o, i)); }
+  MSB_HD MSB_INL int deck_cost(int o, int i) const { return m.ld8(deck_ref(o, i) + 1); }
+  MSB_HD MSB_INL int deck_flags(int o, int i) const { return m.ld8(deck_ref(o, i) + 2); }
+  MSB_HD MSB_INL int deck_x(int o, int i) const { return m.ld8(deck_ref(o, i) + 3); }
+  MSB_HD MSB_INL double deck_w(int o, int i) const { return m.ldf(deck_wref(o, i)); }
+  MSB_HD MSB_INL void set_deck_w(int o, int i, double w) { m.stf(deck_wref(o, i), w); }
   // strength attribute of a card instance in hand/deck (see CF_ALIAS / CF_STR in state.h)
   MSB_HD MSB_INL int inst_strength(int card, int fl, int x) const {
     if (fl & CF_ALIAS) return m.ld16(E_STR + 2 * x);
     if (fl & CF_STR) return x;
     return card < NUM_CARDS ? g_cards[card].strength : 0;
   }
-  MSB_HD MSB_INL int deck_card(int o, int i) const { return m.ld8(pl(o, P_DECK + 4 * i)); }
-  MSB_HD MSB_INL int deck_cost(int o, int i) const { return m.ld8(pl(o, P_DECK + 4 * i + 1)); }
-  MSB_HD MSB_INL int deck_flags(int o, int i) const { return m.ld8(pl(o, P_DECK + 4 * i + 2)); }
-  MSB_HD MSB_INL double deck_w(int o, int i) const { return m.ldf(pl(o, P_WEIGHT + 8 * i)); }
-  MSB_HD MSB_INL void set_deck_w(int o, int i, double w) { m.stf(pl(o, P_WEIGHT + 8 * i), w); }
+  // list primitives -----------------------------------------------------------------------------
+  MSB_HD MSB_INL void deck_remove_at(int o, int j) {   // del deck[j]
+    int n = pl_deck_n(o);
+#if defined(MSB_EXT) && MSB_EXT
+    for (int i = j; i + 1 < n; i++) m.st8(pl(o, P_DECK + i), m.ld8(pl(o, P_DECK + i + 1)));
+#else
+    for (int i = j; i + 1 < n; i++) {
+      m.st32(pl(o, P_DECK + 4 * i), m.ld32(pl(o, P_DECK + 4 * (i + 1))));
+      m.stf(pl(o, P_WEIGHT + 8 * i), m.ldf(pl(o, P_WEIGHT + 8 * (i + 1))));
+    }
+#endif
+    m.st8(pl(o, P_DECK_N), n - 1);
+  }
+  MSB_HD MSB_INL void hand_remove_at(int o, int j) {   // del hand[j]
+    int n = pl_hand_n(o);
+#if defined(MSB_EXT) && MSB_EXT
+    for (int i = j; i + 1 < n; i++) m.st8(pl(o, P_HAND + i), m.ld8(pl(o, P_HAND + i + 1)));
+#else
+    for (int i = j; i + 1 < n; i++) m.st32(pl(o, P_HAND + 4 * i), m.ld32(pl(o, P_HAND + 4 * (i + 1))));
+#endif
+    m.st8(pl(o, P_HAND_N), n - 1);
+  }
+  // hand.append(deck[idx]) (the object keeps living in the deck list until deck.remove)
+  MSB_HD MSB_INL void hand_push_from_deck(int o, int idx) {
+    int hn = pl_hand_n(o);
+    if (hn >= HAND_CAP) {
+      set_fault(FAULT_CAP_HAND);
+      return;
+    }
+#if defined(MSB_EXT) && MSB_EXT
+    m.st8(pl(o, P_HAND + hn), deck_id(o, idx));
+#else
+    m.st32(pl(o, P_HAND + 4 * hn), m.ld32(pl(o, P_DECK + 4 * idx)));
+#endif
+    m.st8(pl(o, P_HAND_N), hn + 1);
+  }
+  // A handle names a card object that has just left a list: the value itself (standard) or its id (extended).
+  MSB_HD MSB_INL uint32_t hand_handle(int o, int i) const {
+#if defined(MSB_EXT) && MSB_EXT
+    return (uint32_t)hand_id(o, i);
+#else
+    return m.ld32(pl(o, P_HAND + 4 * i));
+#endif
+  }
+  // deck.append(obj).  Standard record: a card coming from the hand always has weight 1 (player.py:50).
+  // Extended record: the object keeps whatever weight it has (it may also still be listed in the deck).
+  MSB_HD MSB_INL void deck_push_handle(int o, uint32_t h) {
+    int n = pl_deck_n(o);
+    if (n >= DECK_CAP) {
+      set_fault(FAULT_CAP_DECK);
+      return;
+    }
+#if defined(MSB_EXT) && MSB_EXT
+    m.st8(pl(o, P_DECK + n), (int)h);
+#else
+    m.st32(pl(o, P_DECK + 4 * n), h);
+    m.stf(pl(o, P_WEIGHT + 8 * n), 1.0);
+#endif
+    m.st8(pl(o, P_DECK_N), n + 1);
+  }
+  // a brand-new card object (ua20's copy, b305's returning structure) appended to the deck / hand
+  MSB_HD MSB_NOINLINE void push_new_instance(int o, bool to_hand, int card, int cost, int fl, int x) {
+    int n = to_hand ? pl_hand_n(o) : pl_deck_n(o);
+    if (n >= (to_hand ? HAND_CAP : DECK_CAP)) {
+      set_fault(to_hand ? FAULT_CAP_HAND : FAULT_CAP_DECK);
+      return;
+    }
+    int rec, wrec = -1;
+#if defined(MSB_EXT) && MSB_EXT
+    int id = inst_alloc(o);
+    if (fault()) return;
+    m.st8(pl(o, (to_hand ? P_HAND : P_DECK) + n), id);
+    rec = pl(o, P_INST + 4 * id);
+    wrec = pl(o, P_WEIGHT + 8 * id);
+#else
+    rec = pl(o, (to_hand ? P_HAND : P_DECK) + 4 * n);
+    if (!to_hand) wrec = pl(o, P_WEIGHT + 8 * n);
+#endif
+    m.st8(rec, card);
+    m.st8(rec + 1, cost);
+    m.st8(rec + 2, fl);
+    m.st8(rec + 3, x);
+    if (wrec >= 0) m.stf(wrec, 1.0);
+    m.st8(pl(o, to_hand ? P_HAND_N : P_DECK_N), n + 1);
+  }
 
   MSB_HD MSB_INL int board_at(int tile) const { return m.ld8(OFF_BOARD + tile); }
   MSB_HD MSB_INL void board_put(int tile, int slot) { m.st8(OFF_BOARD + tile, slot); }
@@ -219,14 +329,14 @@ struct Engine {
     for (int o = 0; o < 2; o++) {
       int hn = pl_hand_n(o), dn = pl_deck_n(o);
       for (int i = 0; i < hn + dn; i++) {
-        int off = i < hn ? pl(o, P_HAND + 4 * i) : pl(o, P_DECK + 4 * (i - hn));
+        int off = i < hn ? hand_ref(o, i) : deck_ref(o, i - hn);
         int fl = m.ld8(off + 2);
         if (!(fl & CF_ALIAS)) continue;
         int slot = m.ld8(off + 3);
         if (used & (1u << slot)) continue;
         int str = e_str(slot);
         if (str < 0 || str > 255) {
-          set_fault(FAULT_CAPACITY);
+          set_fault(FAULT_CAP_INST);
           str = 0;
         }
         m.st8(off + 2, (fl & ~CF_ALIAS) | CF_STR);
@@ -235,6 +345,7 @@ struct Engine {
     }
     for (int e = 0; e < NUM_ENT; e++)
       if (!(used & (1u << e))) m.st8(E_CARD + e, CARD_NONE);
+    if (REM_LISTS) rem_collect(used);
     m.st8(H_DEPTH, 0);
   }
   MSB_HD MSB_NOINLINE int new_entity(int card, int owner, int strength, int movement, bool ff) {
@@ -250,6 +361,91 @@ struct Engine {
     e_set_str(e, strength);
     e_set_dmg(e, 0);
     m.st32(E_PATH + 4 * e, 0);
+    if (REM_LISTS) m.st8(E_REM + e, REM_NONE);
+    return e;
+  }
+
+  // ---- b005's remembered deep copies (extended record only) ---------------------------------
+  MSB_HD MSB_INL int rem_off(int list) const { return OFF_REM + list * REM_LIST_BYTES; }
+  MSB_HD MSB_INL int rem_rec(int list, int i) const { return rem_off(list) + 4 + i * REM_REC; }
+  MSB_HD MSB_INL int rem_alloc() {
+    for (int l = 0; l < REM_LISTS; l++)
+      if (m.ld8(rem_off(l) + 1) == 0) {
+        m.st8(rem_off(l), 0);
+        m.st8(rem_off(l) + 1, 1);
+        m.st8(rem_off(l) + 2, 0);
+        return l;
+      }
+    set_fault(FAULT_CAP_REM);
+    return REM_NONE;
+  }
+  MSB_HD void rem_mark(int list, uint32_t& live) {
+    if (list == REM_NONE || (live & (1u << list))) return;
+    live |= 1u << list;
+    int n = m.ld8(rem_off(list));
+    for (int i = 0; i < n; i++) rem_mark(m.ld8(rem_rec(list, i) + 11), live);
+  }
+  // lists reachable from a b005 on the board survive the step; everything else is garbage
+  MSB_HD MSB_NOINLINE void rem_collect(uint32_t used) {
+    uint32_t live = 0;
+    for (int e = 0; e < NUM_ENT; e++)
+      if (used & (1u << e)) rem_mark(m.ld8(E_REM + e), live);
+    for (int l = 0; l < REM_LISTS; l++)
+      if (!(live & (1u << l))) m.st8(rem_off(l) + 1, 0);
+  }
+  // copy.deepcopy of a remembered list, nested memories included
+  MSB_HD int rem_deep_copy(int src, int depth) {
+    if (src == REM_NONE) return REM_NONE;
+    if (depth > 6) {
+      set_fault(FAULT_CAP_REM);
+      return REM_NONE;
+    }
+    int dst = rem_alloc();
+    if (fault()) return REM_NONE;
+    int n = m.ld8(rem_off(src));
+    m.st8(rem_off(dst), n);
+    // The reference's deepcopy reaches the whole game through entity.player (card.py:72): entities inside
+    // a NESTED memory keep a copied Player whose board is a frozen duplicate.  Restoring such an entity
+    // makes it act on that phantom board, which this record cannot express: the list is marked and a
+    // restore from it raises FAULT_UNSUPPORTED (needs two adjacent b005 of one owner).
+    m.st8(rem_off(dst) + 2, 1);
+    for (int k = 0; k < n && !fault(); k++) {
+      for (int b = 0; b < REM_REC - 1; b++) m.st8(rem_rec(dst, k) + b, m.ld8(rem_rec(src, k) + b));
+      m.st8(rem_rec(dst, k) + 11, rem_deep_copy(m.ld8(rem_rec(src, k) + 11), depth + 1));
+    }
+    return dst;
+  }
+  // deep copy of entity e into record i of `list` (Card.copy, card.py:71-75)
+  MSB_HD MSB_NOINLINE void rem_snapshot(int list, int i, int e) {
+    int r = rem_rec(list, i);
+    m.st8(r + 0, e_card(e));
+    m.st8(r + 1, e_flags(e));
+    m.st8(r + 2, m.ld8(E_POS + e));
+    m.st8(r + 3, e_mov(e));
+    for (int s = 0; s < 5; s++) m.st8(r + 4 + s, e_st(e, s));
+    int str = e_str(e);
+    m.st8(r + 9, str & 0xff);
+    m.st8(r + 10, (str >> 8) & 0xff);
+    int nested = rem_deep_copy(m.ld8(E_REM + e), 0);   // a remembered b005 carries a deep copy of its own memory
+    if (fault()) return;
+    m.st8(r + 11, nested);
+  }
+  // board.set(entity.position, entity) with a remembered copy: a NEW object enters the board
+  MSB_HD MSB_NOINLINE int rem_instantiate(int list, int i) {
+    int r = rem_rec(list, i);
+    if (m.ld8(rem_off(list) + 2)) {
+      set_fault(FAULT_UNSUPPORTED);
+      return 0;
+    }
+    int card = m.ld8(r);
+    int fl = m.ld8(r + 1);
+    int str = (int16_t)(m.ld8(r + 9) | (m.ld8(r + 10) << 8));
+    int e = new_entity(card, fl & EF_OWNER, str, m.ld8(r + 3), (fl & EF_FF) != 0);
+    if (fault()) return e;
+    m.st8(E_FLAGS + e, fl);
+    for (int s = 0; s < 5; s++) m.st8(E_ST + s * NUM_ENT + e, m.ld8(r + 4 + s));
+    m.st8(E_REM + e, m.ld8(r + 11));   // the nested memory now belongs to the restored object
+    board_set(tile_p(m.ld8(r + 2)), e);
     return e;
   }
 
@@ -678,7 +874,7 @@ struct Engine {
         packed |= (uint32_t)p_pack(enc) << (8 * n);
         n++;
       } else {
-        set_fault(FAULT_CAPACITY);
+        set_fault(FAULT_CAP_PATH);
       }
       position = dest;
     }
@@ -859,7 +1055,7 @@ struct Engine {
       n++;
     }
     if (n > PATH_CAP) {
-      set_fault(FAULT_CAPACITY);
+      set_fault(FAULT_CAP_PATH);
       return;
     }
     if (n > 0) {
@@ -899,13 +1095,15 @@ struct Engine {
   // list.remove(target): index of the first element EQUAL to the one at `idx`.  Unit/Structure
   // equality is (card_id, player, position); instances that came back from the board (b305) have a
   // position, fresh cards have None: comparing None with a Point raises (point.py:6-7).
-  MSB_HD MSB_INL int first_equal(int base_off, int idx) {
-    int card = m.ld8(base_off + 4 * idx);
-    if (!card_eq_by_id(card)) return idx;
-    int positioned = m.ld8(base_off + 4 * idx + 2) & (CF_ALIAS | CF_STR);
+  MSB_HD MSB_INL int first_equal(int o, bool in_hand, int idx) {
+    int tref = in_hand ? hand_ref(o, idx) : deck_ref(o, idx);
+    int card = m.ld8(tref);
+    int positioned = m.ld8(tref + 2) & (CF_ALIAS | CF_STR);
     for (int i = 0; i < idx; i++) {
-      if (m.ld8(base_off + 4 * i) != card) continue;
-      int pi = m.ld8(base_off + 4 * i + 2) & (CF_ALIAS | CF_STR);
+      int r = in_hand ? hand_ref(o, i) : deck_ref(o, i);
+      if (r == tref) return i;   // the very same object listed earlier (extended record only)
+      if (!card_eq_by_id(card) || m.ld8(r) != card) continue;
+      int pi = m.ld8(r + 2) & (CF_ALIAS | CF_STR);
       if (!pi && !positioned) return i;
       set_fault((pi && positioned) ? FAULT_UNSUPPORTED : FAULT_PY_EXCEPTION);
       return idx;
@@ -939,22 +1137,12 @@ struct Engine {
         set_fault(FAULT_PY_EXCEPTION);
         return;
       }
-      set_deck_w(o, idx, 1.0);
-      int hn = pl_hand_n(o);
-      if (hn >= HAND_CAP) {
-        set_fault(FAULT_CAPACITY);
-        return;
-      }
-      m.st32(pl(o, P_HAND + 4 * hn), m.ld32(pl(o, P_DECK + 4 * idx)));
-      m.st8(pl(o, P_HAND_N), hn + 1);
-      // deck.remove(choice): first EQUAL element
-      int j = first_equal(pl(o, P_DECK), idx);
+      set_deck_w(o, idx, 1.0);             // choice.weight = 1
+      hand_push_from_deck(o, idx);         // self.hand.append(choice)
       if (fault()) return;
-      for (int i = j; i + 1 < n; i++) {
-        m.st32(pl(o, P_DECK + 4 * i), m.ld32(pl(o, P_DECK + 4 * (i + 1))));
-        set_deck_w(o, i, deck_w(o, i + 1));
-      }
-      m.st8(pl(o, P_DECK_N), n - 1);
+      int j = first_equal(o, false, idx);  // self.deck.remove(choice): first EQUAL element
+      if (fault()) return;
+      deck_remove_at(o, j);
     }
   }
   // Player.fill_hand, player.py:54-55
@@ -965,24 +1153,13 @@ struct Engine {
   // Player.discard, player.py:57-66 (reweight: w*1.6+100 for every deck card)
   MSB_HD MSB_NOINLINE void discard(int o, int hand_index) {
     int n = pl_deck_n(o);
-    for (int i = 0; i < n; i++) set_deck_w(o, i, deck_w(o, i) * 1.6 + 100);
-    uint32_t inst = m.ld32(pl(o, P_HAND + 4 * hand_index));
+    for (int i = 0; i < n; i++) set_deck_w(o, i, deck_w(o, i) * 1.6 + 100);   // per list position
+    uint32_t target = hand_handle(o, hand_index);
     int fl = hand_flags(o, hand_index);
-    // hand.remove(target): first equal
-    int j = first_equal(pl(o, P_HAND), hand_index);
+    int j = first_equal(o, true, hand_index);   // hand.remove(target): first equal
     if (fault()) return;
-    int hn = pl_hand_n(o);
-    for (int i = j; i + 1 < hn; i++) m.st32(pl(o, P_HAND + 4 * i), m.ld32(pl(o, P_HAND + 4 * (i + 1))));
-    m.st8(pl(o, P_HAND_N), hn - 1);
-    if (!(fl & CF_SINGLE_USE)) {
-      if (n >= DECK_CAP) {
-        set_fault(FAULT_CAPACITY);
-        return;
-      }
-      m.st32(pl(o, P_DECK + 4 * n), inst);
-      set_deck_w(o, n, 1.0);  // hand cards always carry weight 1 (player.py:50)
-      m.st8(pl(o, P_DECK_N), n + 1);
-    }
+    hand_remove_at(o, j);
+    if (!(fl & CF_SINGLE_USE)) deck_push_handle(o, target);
   }
   // Board.add_to_history, board.py:324-325 (only the last four are observable)
   MSB_HD MSB_INL void add_history(int owner, int card) {
@@ -1183,9 +1360,15 @@ struct Engine {
       m.st8(pl(lo, P_FLAGS), m.ld8(pl(lo, P_FLAGS)) & ~1);
     } else if (action < 155) {
       int ci = action - 151;
+#if defined(MSB_EXT) && MSB_EXT
+      int a = hand_id(lo, ci), b = hand_id(lo, 0);
+      m.st8(pl(lo, P_HAND + ci), b);
+      m.st8(pl(lo, P_HAND), a);
+#else
       uint32_t a = m.ld32(pl(lo, P_HAND + 4 * ci)), b = m.ld32(pl(lo, P_HAND));
       m.st32(pl(lo, P_HAND + 4 * ci), b);
       m.st32(pl(lo, P_HAND), a);
+#endif
       m.st8(pl(lo, P_FLAGS), m.ld8(pl(lo, P_FLAGS)) & ~2);
     }
     if (fault()) return;
@@ -1206,6 +1389,8 @@ struct Engine {
     for (int w = 0; w < STATE_WORDS; w++) m.st32(4 * w, 0);
     for (int t = 0; t < 20; t++) board_put(t, SLOT_NONE);
     for (int e = 0; e < NUM_ENT; e++) m.st8(E_CARD + e, CARD_NONE);
+    if (REM_LISTS)
+      for (int e = 0; e < NUM_ENT; e++) m.st8(E_REM + e, REM_NONE);
     for (int i = 0; i < 4; i++) {
       m.st8(H_HIST + 2 * i, 0xff);
       m.st8(H_HIST + 2 * i + 1, 0xff);
@@ -1219,23 +1404,29 @@ struct Engine {
       m.st8(pl(o, P_FRONT), o == 0 ? 4 : 0);
       m.st8(pl(o, P_FLAGS), 3);
       m.st8(pl(o, P_FACTION), o == 0 ? faction0 : faction1);
-      uint8_t d[DECK_CAP];
-      for (int i = 0; i < DECK_CAP; i++) d[i] = deck[i];
-      for (int i = DECK_CAP - 1; i >= 1; i--) {  // random.shuffle(self.deck)
+      uint8_t d[DECK_SIZE];
+      for (int i = 0; i < DECK_SIZE; i++) d[i] = deck[i];
+      for (int i = DECK_SIZE - 1; i >= 1; i--) {  // random.shuffle(self.deck)
         int j = (int)rng.interval((uint32_t)i);
         uint8_t tmp = d[i];
         d[i] = d[j];
         d[j] = tmp;
       }
       double w = 1.0;
-      for (int i = 0; i < DECK_CAP; i++) {
+      for (int i = 0; i < DECK_SIZE; i++) {
         if (i > 0) w = w * 1.6 + 100;
-        m.st8(pl(o, P_DECK + 4 * i), d[i]);
-        m.st8(pl(o, P_DECK + 4 * i + 1), g_cards[d[i]].cost);
-        m.st8(pl(o, P_DECK + 4 * i + 2), g_cards[d[i]].ff ? CF_FF : 0);
+#if defined(MSB_EXT) && MSB_EXT
+        m.st8(pl(o, P_DECK + i), i);   // object i sits at deck position i
+#endif
+        m.st8(pl(o, P_DECK_N), i + 1);
+        int r = deck_ref(o, i);
+        m.st8(r, d[i]);
+        m.st8(r + 1, g_cards[d[i]].cost);
+        m.st8(r + 2, g_cards[d[i]].ff ? CF_FF : 0);
+        m.st8(r + 3, 0);
         set_deck_w(o, i, w);
       }
-      m.st8(pl(o, P_DECK_N), DECK_CAP);
+      m.st8(pl(o, P_DECK_N), DECK_SIZE);
       fill_hand(o);
     }
     if (rng.overrun) set_fault(FAULT_RNG_OVERRUN);

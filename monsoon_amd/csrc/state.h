@@ -22,7 +22,20 @@ namespace msb {
 
 constexpr int NUM_ENT = 28;    // 20 tiles + 8 transient (dead / displaced / spawned this step)
 constexpr int HAND_CAP = 5;    // 4, transiently 5 (b305 returns itself to hand)
-constexpr int DECK_CAP = 12;   // 12-card decks; ua20's extra single-use cards need a larger build
+constexpr int DECK_SIZE = 12;  // cards per deck at construction (games/stormbound.py:295-302)
+// Two builds of the same source.  The standard record holds every card except ua20 and b005; the
+// EXTENDED record (-DMSB_EXT=1: libmonsoon_hip_ext.so / liboracle_ext.so) adds room for ua20's extra
+// single-use deck cards (cards/ua20.py:27-32) and for b005's remembered deep copies (cards/b005.py:14-33).
+#if defined(MSB_EXT) && MSB_EXT
+constexpr int DECK_CAP = 24;
+constexpr int REM_LISTS = 10;  // snapshot lists (one per b005 with a pending memory, nested ones included)
+#else
+constexpr int DECK_CAP = 12;
+constexpr int REM_LISTS = 0;
+#endif
+constexpr int REM_PER_LIST = 8;   // surrounding tiles
+constexpr int REM_REC = 12;       // card, flags, pos, mov, st[5], strength i16, nested list id
+constexpr int REM_NONE = 0xFF;
 constexpr int TRIG_CAP = 20;
 constexpr int PATH_CAP = 4;    // max movement among the cards (u069=4; gain_speed gives <= 3)
 constexpr int SLOT_NONE = 0xFF;
@@ -52,10 +65,23 @@ constexpr int P_FLAGS = 7;      // b0 replacable, b1 leftmost_movable
 constexpr int P_FACTION = 8;
 constexpr int P_HAND_N = 9;
 constexpr int P_DECK_N = 10;
-constexpr int P_HAND = 12;                      // HAND_CAP x {card, cost, flags, pad}
-constexpr int P_DECK = P_HAND + 4 * HAND_CAP;   // DECK_CAP x {card, cost, flags, pad}
-constexpr int P_WEIGHT = (P_DECK + 4 * DECK_CAP + 7) & ~7;  // DECK_CAP x f64
+#if defined(MSB_EXT) && MSB_EXT
+// Extended record: hand and deck are lists of OBJECT ids into a per-player card-instance table, because
+// ua20's duplicate structures make list.remove() take a different (equal) object than the one drawn
+// (player.py:52, structure.py:18-19): the same object can then sit in the hand and in the deck, or twice
+// in the deck, and Player.reweight (player.py:57-59) touches it once per list position.
+constexpr int INST_CAP = 32;
+constexpr int P_HAND = 12;                       // HAND_CAP x u8 instance id
+constexpr int P_DECK = P_HAND + HAND_CAP;        // DECK_CAP x u8 instance id
+constexpr int P_INST = (P_DECK + DECK_CAP + 3) & ~3;          // INST_CAP x {card, cost, flags, x}
+constexpr int P_WEIGHT = (P_INST + 4 * INST_CAP + 7) & ~7;    // INST_CAP x f64 (Card.weight)
+constexpr int PL_SIZE = P_WEIGHT + 8 * INST_CAP;
+#else
+constexpr int P_HAND = 12;                      // HAND_CAP x {card, cost, flags, x}
+constexpr int P_DECK = P_HAND + 4 * HAND_CAP;   // DECK_CAP x {card, cost, flags, x}
+constexpr int P_WEIGHT = (P_DECK + 4 * DECK_CAP + 7) & ~7;  // DECK_CAP x f64 (weight of the card at that deck position)
 constexpr int PL_SIZE = P_WEIGHT + 8 * DECK_CAP;
+#endif
 static_assert((OFF_PL % 8) == 0 && (PL_SIZE % 8) == 0, "f64 alignment");
 // card-instance flags (hand/deck entries {card, cost, flags, x}).  b305 puts the on-board structure OBJECT
 // back into the hand (cards/b305.py:40-45): such an entry aliases entity slot x while that entity is
@@ -75,7 +101,10 @@ constexpr int E_PATHN = E_MOVEID + NUM_ENT;     // u8 len(path)
 constexpr int E_STR = (E_PATHN + NUM_ENT + 1) & ~1;   // i16 strength
 constexpr int E_DMG = E_STR + 2 * NUM_ENT;      // i16 damage_taken
 constexpr int E_PATH = (E_DMG + 2 * NUM_ENT + 3) & ~3;  // u32 packed path (PATH_CAP bytes)
-constexpr int STATE_BYTES = (E_PATH + 4 * NUM_ENT + 7) & ~7;
+constexpr int E_REM = E_PATH + 4 * NUM_ENT;                       // u8[NUM_ENT]: b005's list id (REM_NONE = [])
+constexpr int OFF_REM = (E_REM + (REM_LISTS ? NUM_ENT : 0) + 3) & ~3; // REM_LISTS x {n, used, pad2, REM_PER_LIST x REM_REC}
+constexpr int REM_LIST_BYTES = 4 + REM_PER_LIST * REM_REC;
+constexpr int STATE_BYTES = (OFF_REM + REM_LISTS * REM_LIST_BYTES + 7) & ~7;
 constexpr int STATE_WORDS = STATE_BYTES / 4;
 constexpr int EF_OWNER = 1, EF_FF = 2, EF_RESOLVING_PLAY = 4, EF_SINGLE_USE = 8;
 

@@ -12,8 +12,10 @@ def _ptr(a):
 
 
 class BatchEngine:
-    def __init__(self, max_games, device=0, lanes_per_game=0, stack_bytes=0):
-        self.lib = _lib.load()
+    def __init__(self, max_games, device=0, lanes_per_game=0, stack_bytes=0, extended=False):
+        """extended=True loads the build with the larger per-game record (decks holding ua20 / b005)."""
+        self.lib = _lib.load(extended)
+        self.extended = extended
         self.h = ctypes.c_void_p()
         cfg = Config(device, max_games, lanes_per_game, stack_bytes)
         rc = self.lib.monsoon_create(ctypes.byref(cfg), ctypes.byref(self.h))
@@ -38,7 +40,7 @@ class BatchEngine:
             pass
 
     def _ck(self, rc, what):
-        _lib.check(self.h, rc, what)
+        _lib.check(self.h, rc, what, self.lib)
 
     # ---- Seam G, batched ------------------------------------------------------------------
     def reset(self, seeds, decks, factions=None):

@@ -21,14 +21,15 @@ import harness as H  # noqa: E402
 
 from evo.features import StateFeatures  # noqa: E402
 
-LIB = ctypes.CDLL(os.path.join(H.REPO, "oracle", "liboracle.so"))
+EXT = os.environ.get("MSB_EXT", "0") == "1"   # MSB_EXT=1: extended record (ua20, b005)
+LIB = ctypes.CDLL(os.path.join(H.REPO, "oracle", "liboracle_ext.so" if EXT else "liboracle.so"))
 LIB.orc_create.restype = ctypes.c_void_p
 LIB.orc_canon_hash.restype = ctypes.c_uint64
 for name in ("orc_reset", "orc_legal", "orc_step", "orc_observe", "orc_features", "orc_canon", "orc_destroy",
              "orc_canon_hash", "orc_have_winner", "orc_to_play", "orc_decide"):
     getattr(LIB, name).argtypes = None
 
-UNSUPPORTED = {"ua20", "b005"}
+UNSUPPORTED = set() if EXT else {"ua20", "b005"}
 FAULT_CARDS = {"up01", "up02", "up03"}
 
 

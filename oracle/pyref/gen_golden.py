@@ -9,7 +9,8 @@ by running it here and committing inputs + expected outputs (data only, no refer
   score_kat.npz            G4  HeuristicAgent score for random (w, f_before, f_after) via np.dot
   trace_random_<deck>.npz  G3  seeded random-policy games: legal masks, action, state hash,
                                observation hash, reward, done (+ features for N12M)
-  trace_pool.npz           G3/G5 random 12-card decks from every supported card (card coverage)
+  trace_pool.npz           G3/G5 random 12-card decks from the 107 cards of the standard record (card coverage)
+  trace_pool_ext.npz       G3/G5 the same over all 109 observable cards (ua20, b005: extended record)
   trace_heuristic_N12M.npz G3  corrected heuristic self-play (SURVEY §8c contract), W0 both sides:
                                chosen action, best score, score hash, state hash per decision
   initial_states.npz       G2  canonical records right after construction
@@ -170,11 +171,11 @@ def gen_random(deck, deck2, n_games, steps, jobs, want_feat=False, seed0=0):
     pack_traces(f"trace_random_{deck}.npz", jobs, results, [idx(d0)] * n_games, [idx(d1)] * n_games)
 
 
-def gen_pool(n_games, steps, jobs):
-    pool = [c for c in H.CARD_IDS if c not in UNSUPPORTED and c not in FAULT_CARDS]
+def gen_pool(n_games, steps, jobs, ext=False):
+    pool = [c for c in H.CARD_IDS if (ext or c not in UNSUPPORTED) and c not in FAULT_CARDS]
     tasks, decks0, decks1 = [], [], []
     for k in range(n_games):
-        seed = 5000 + k
+        seed = (30000 if ext else 5000) + k
         rs = np.random.RandomState(seed ^ 0x9E3779B9)
         d0 = list(rs.choice(pool, 12, replace=False))
         d1 = list(rs.choice(pool, 12, replace=False))
@@ -183,7 +184,7 @@ def gen_pool(n_games, steps, jobs):
         decks1.append(idx(d1))
     with ProcessPoolExecutor(jobs) as ex:
         results = list(ex.map(random_trace, tasks))
-    pack_traces("trace_pool.npz", jobs, results, decks0, decks1)
+    pack_traces("trace_pool_ext.npz" if ext else "trace_pool.npz", jobs, results, decks0, decks1)
 
 
 # ---------------------------------------------------------------------------------------------
@@ -290,6 +291,8 @@ def main():
         "random_N12M": lambda: gen_random("N12M", None, 48, 300, args.jobs, want_feat=True),
         "random_IRONCLAD": lambda: gen_random("IRONCLAD", "SWARM", 32, 300, args.jobs),
         "pool": lambda: gen_pool(160, 300, args.jobs),
+        "pool_ext": lambda: gen_pool(120, 300, args.jobs, ext=True),   # all 109 observable cards (ua20, b005 included)
+        "random_S12": lambda: gen_random("S12", None, 48, 300, args.jobs),
         "heuristic": lambda: gen_heuristic(12, 200, args.jobs),
     }
     for name, fn in todo.items():

@@ -11,21 +11,22 @@ import numpy as np
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ORACLE_DIR = os.path.join(REPO, "oracle")
 LIB_PATH = os.path.join(ORACLE_DIR, "liboracle.so")
+LIB_PATH_EXT = os.path.join(ORACLE_DIR, "liboracle_ext.so")   # extended record (ua20, b005)
 
 
 def build():
-    subprocess.run(["make", "-C", ORACLE_DIR, "-s"], check=True)
+    subprocess.run(["make", "-C", ORACLE_DIR, "-s", "all"], check=True)
 
 
-_lib = None
+_libs = {}
 
 
-def lib():
-    global _lib
-    if _lib is None:
-        if not os.path.exists(LIB_PATH):
+def lib(extended=False):
+    if extended not in _libs:
+        path = LIB_PATH_EXT if extended else LIB_PATH
+        if not os.path.exists(path):
             build()
-        L = ctypes.CDLL(LIB_PATH)
+        L = ctypes.CDLL(path)
         L.orc_create.restype = ctypes.c_void_p
         L.orc_create.argtypes = [ctypes.c_int]
         L.orc_destroy.argtypes = [ctypes.c_void_p]
@@ -54,8 +55,8 @@ def lib():
         L.orc_rng_random.argtypes = [ctypes.c_uint32, ctypes.c_int, ctypes.c_void_p]
         L.orc_rng_randint.argtypes = [ctypes.c_uint32, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
         L.orc_rng_shuffle.argtypes = [ctypes.c_uint32, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
-        _lib = L
-    return _lib
+        _libs[extended] = L
+    return _libs[extended]
 
 
 def _p(a):
@@ -72,8 +73,8 @@ def fnv1a64(data):
 class Oracle:
     """n independent games replayed on the CPU."""
 
-    def __init__(self, n=1):
-        self.L = lib()
+    def __init__(self, n=1, extended=False):
+        self.L = lib(extended)
         self.h = ctypes.c_void_p(self.L.orc_create(n))
         self.n = n
 
