@@ -36,7 +36,10 @@ using namespace msb;
 
 namespace {
 
-constexpr int SW = (STATE_WORDS + 3) & ~3;   // record stride in HBM, words (16-byte aligned)
+constexpr int SW = STATE_WORDS;               // record stride in HBM, words (STATE_BYTES is a multiple of 16)
+constexpr int SG = STATE_BYTES / 16;         // 16-byte granules per record
+static_assert(STATE_BYTES % 16 == 0, "record must be whole granules");
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 constexpr int RNG_WORDS = 2 * MT_N;          // tempered outputs: two blocks per game
 
 struct GameMeta {
@@ -139,18 +142,26 @@ constexpr int API_LANES = 32;
 constexpr int API_LANES = 64;
 #endif
 struct ApiLds {
-  uint32_t w[SW * API_LANES];
+  u32x4 g[SG * API_LANES];
 };
 #define API_GAME_INDEX()                                  \
   if ((int)threadIdx.x >= API_LANES) return;              \
   int g = blockIdx.x * API_LANES + threadIdx.x;           \
   if (g >= n) return;
 
-__device__ MSB_INL void api_load(MSB_AS_LDS uint32_t* col, const uint32_t* src) {
-  for (int w = 0; w < STATE_WORDS; w++) col[w * API_LANES] = src[w];
+__device__ MSB_INL LdsMem api_mem(ApiLds& lds) {
+  LdsMem m;
+  m.base = (MSB_AS_LDS uint8_t*)lds.g + threadIdx.x * 16;
+  m.stride = API_LANES * 16;
+  return m;
 }
-__device__ MSB_INL void api_store(uint32_t* dst, MSB_AS_LDS const uint32_t* col) {
-  for (int w = 0; w < STATE_WORDS; w++) dst[w] = col[w * API_LANES];
+__device__ MSB_INL void api_load(const LdsMem& m, const uint32_t* src) {
+  const u32x4* s4 = (const u32x4*)src;
+  for (int c = 0; c < SG; c++) *(MSB_AS_LDS u32x4*)(m.base + c * m.stride) = s4[c];
+}
+__device__ MSB_INL void api_store(uint32_t* dst, const LdsMem& m) {
+  u32x4* d4 = (u32x4*)dst;
+  for (int c = 0; c < SG; c++) d4[c] = *(MSB_AS_LDS const u32x4*)(m.base + c * m.stride);
 }
 
 __global__ void __launch_bounds__(64) k_seed(DevBuffers b, int n, const uint32_t* seeds) {
@@ -180,8 +191,7 @@ __global__ void __launch_bounds__(64) k_init(DevBuffers b, int n, const uint8_t*
   __shared__ ApiLds lds;
   API_GAME_INDEX();
   Engine<LdsMem> e;
-  e.m.base = (MSB_AS_LDS uint32_t*)lds.w + threadIdx.x;
-  e.m.stride = API_LANES;
+  e.m = api_mem(lds);
   GameMeta m = b.meta[g];
   m.rng = 0;
   e.rng = make_view(b, g, m.rng);
@@ -198,16 +208,15 @@ __global__ void __launch_bounds__(64) k_init(DevBuffers b, int n, const uint8_t*
   m.steps = 0;
   m.lookahead = 0;
   b.meta[g] = m;
-  api_store(b.state + (size_t)g * SW, e.m.base);
+  api_store(b.state + (size_t)g * SW, e.m);
 }
 
 __global__ void __launch_bounds__(64) k_legal(DevBuffers b, int n, uint64_t* out) {
   __shared__ ApiLds lds;
   API_GAME_INDEX();
   Engine<LdsMem> e;
-  e.m.base = (MSB_AS_LDS uint32_t*)lds.w + threadIdx.x;
-  e.m.stride = API_LANES;
-  api_load(e.m.base, b.state + (size_t)g * SW);
+  e.m = api_mem(lds);
+  api_load(e.m, b.state + (size_t)g * SW);
   uint64_t mask[3];
   e.legal_mask(mask);
   out[3 * g] = mask[0];
@@ -226,9 +235,8 @@ __global__ void __launch_bounds__(64) k_step(DevBuffers b, int n, const uint8_t*
   illegal[g] = 0;
   if (a == 255) return;
   Engine<LdsMem> e;
-  e.m.base = (MSB_AS_LDS uint32_t*)lds.w + threadIdx.x;
-  e.m.stride = API_LANES;
-  api_load(e.m.base, b.state + (size_t)g * SW);
+  e.m = api_mem(lds);
+  api_load(e.m, b.state + (size_t)g * SW);
   uint64_t mask[3];
   e.legal_mask(mask);
   if (a >= 156 || !((mask[a >> 6] >> (a & 63)) & 1)) {
@@ -247,16 +255,15 @@ __global__ void __launch_bounds__(64) k_step(DevBuffers b, int n, const uint8_t*
   m.last_action = (uint8_t)a;
   if (e.fault()) m.fault = (uint8_t)e.fault();
   b.meta[g] = m;
-  api_store(b.state + (size_t)g * SW, e.m.base);
+  api_store(b.state + (size_t)g * SW, e.m);
 }
 
 __global__ void __launch_bounds__(64) k_observe(DevBuffers b, int n, int32_t* out, uint8_t* raises) {
   __shared__ ApiLds lds;
   API_GAME_INDEX();
   Engine<LdsMem> e;
-  e.m.base = (MSB_AS_LDS uint32_t*)lds.w + threadIdx.x;
-  e.m.stride = API_LANES;
-  api_load(e.m.base, b.state + (size_t)g * SW);
+  e.m = api_mem(lds);
+  api_load(e.m, b.state + (size_t)g * SW);
   bool r = e.observation_raises();
   raises[g] = r ? 1 : 0;
   if (!r) e.observe(out + (size_t)g * MONSOON_OBS_INTS);
@@ -266,9 +273,8 @@ __global__ void __launch_bounds__(64) k_features(DevBuffers b, int n, double* ou
   __shared__ ApiLds lds;
   API_GAME_INDEX();
   Engine<LdsMem> e;
-  e.m.base = (MSB_AS_LDS uint32_t*)lds.w + threadIdx.x;
-  e.m.stride = API_LANES;
-  api_load(e.m.base, b.state + (size_t)g * SW);
+  e.m = api_mem(lds);
+  api_load(e.m, b.state + (size_t)g * SW);
   double f[10];
   if (e.observation_raises()) {
     for (int i = 0; i < 10; i++) f[i] = NAN;
@@ -294,9 +300,8 @@ __global__ void __launch_bounds__(64) k_export(DevBuffers b, int g, uint8_t* out
   __shared__ ApiLds lds;
   if (threadIdx.x != 0) return;
   Engine<LdsMem> e;
-  e.m.base = (MSB_AS_LDS uint32_t*)lds.w;
-  e.m.stride = API_LANES;
-  api_load(e.m.base, b.state + (size_t)g * SW);
+  e.m = api_mem(lds);
+  api_load(e.m, b.state + (size_t)g * SW);
   RngView v = make_view(b, g, b.meta[g].rng);
   uint32_t nx = v.next_u32();
   *len = canon_record(e, nx, out);
@@ -306,9 +311,8 @@ __global__ void __launch_bounds__(64) k_hash(DevBuffers b, int n, uint64_t* out)
   __shared__ ApiLds lds;
   API_GAME_INDEX();
   Engine<LdsMem> e;
-  e.m.base = (MSB_AS_LDS uint32_t*)lds.w + threadIdx.x;
-  e.m.stride = API_LANES;
-  api_load(e.m.base, b.state + (size_t)g * SW);
+  e.m = api_mem(lds);
+  api_load(e.m, b.state + (size_t)g * SW);
   RngView v = make_view(b, g, b.meta[g].rng);
   uint32_t nx = v.next_u32();
   uint8_t rec[CANON_MAX];
@@ -334,10 +338,10 @@ __device__ MSB_INL int nth_set_bit(const uint64_t mask[3], int k) {
 
 template <int U, int WPE>
 __global__ void __launch_bounds__(64, WPE) k_decide(DevBuffers b, int n, int max_turns, int write_scores) {
-  constexpr int PRIV_WORDS = SW * U > MT_N ? SW * U : MT_N;   // the private region doubles as the twist buffer
-  __shared__ uint32_t s_par[SW];
-  __shared__ uint32_t s_priv[PRIV_WORDS];
-  __shared__ uint32_t s_best[SW];
+  constexpr int PRIV_G = SG * U > (MT_N + 3) / 4 ? SG * U : (MT_N + 3) / 4;   // the private region doubles as the twist buffer
+  __shared__ u32x4 s_par[SG];
+  __shared__ u32x4 s_priv[PRIV_G];
+  __shared__ u32x4 s_best[SG];
   const int g = blockIdx.x;
   const int lane = threadIdx.x;
   if (g >= n) return;
@@ -349,15 +353,15 @@ __global__ void __launch_bounds__(64, WPE) k_decide(DevBuffers b, int n, int max
     }
     return;
   }
-  MSB_AS_LDS uint32_t* par = (MSB_AS_LDS uint32_t*)s_par;
-  MSB_AS_LDS uint32_t* priv = (MSB_AS_LDS uint32_t*)s_priv;
-  uint32_t* grec = b.state + (size_t)g * SW;
-  for (int w = lane; w < SW; w += 64) par[w] = grec[w];
+  MSB_AS_LDS u32x4* par = (MSB_AS_LDS u32x4*)s_par;
+  MSB_AS_LDS u32x4* priv = (MSB_AS_LDS u32x4*)s_priv;
+  u32x4* grec = (u32x4*)(b.state + (size_t)g * SW);
+  for (int c = lane; c < SG; c += 64) par[c] = grec[c];   // one coalesced 16-B-per-lane pass
   __syncthreads();
 
   Engine<LdsMem> pe;
-  pe.m.base = par;
-  pe.m.stride = 1;
+  pe.m.base = (MSB_AS_LDS uint8_t*)par;
+  pe.m.stride = 16;
   pe.rng = make_view(b, g, meta.rng);
 
   // rollout contract: while not have_winner() and steps < max_turns
@@ -386,8 +390,8 @@ __global__ void __launch_bounds__(64, WPE) k_decide(DevBuffers b, int n, int max
   for (int i = 0; i < 10; i++) w[i] = wt[i];
 
   Engine<LdsMem> ce;
-  ce.m.base = priv + lane;
-  ce.m.stride = U;
+  ce.m.base = (MSB_AS_LDS uint8_t*)(priv + lane);
+  ce.m.stride = U * 16;
   // Running best over the passes (uniform across the wave).  When the legal set needs more than
   // one pass, the best successor so far is parked in a spare LDS column so that nothing is replayed.
   constexpr int NONE_A = 1 << 20;
@@ -397,7 +401,7 @@ __global__ void __launch_bounds__(64, WPE) k_decide(DevBuffers b, int n, int max
   int cfault = 0;
   int wl = 0;                       // column (lane) holding the committed successor
   const bool multi = n_legal > U;
-  MSB_AS_LDS uint32_t* bestcol = (MSB_AS_LDS uint32_t*)s_best;
+  MSB_AS_LDS u32x4* bestcol = (MSB_AS_LDS u32x4*)s_best;
   for (int base = 0; base < n_legal; base += U) {
     int k = base + lane;
     double s = 0.0;   // except Exception -> 0.0 (evo/heuristic_agent.py:48-51)
@@ -406,7 +410,7 @@ __global__ void __launch_bounds__(64, WPE) k_decide(DevBuffers b, int n, int max
     int my_fault = 0;
     if (lane < U && k < n_legal) {
       a = nth_set_bit(mask, k);
-      for (int i = 0; i < STATE_WORDS; i++) priv[i * U + lane] = par[i];
+      for (int c = 0; c < SG; c++) priv[c * U + lane] = par[c];   // copy.deepcopy: 16 bytes per LDS op
       ce.rng = pe.rng;
       int r, d;
       ce.step(a, &r, &d);
@@ -442,7 +446,7 @@ __global__ void __launch_bounds__(64, WPE) k_decide(DevBuffers b, int n, int max
       cfault = __shfl(my_fault, wl);
       if (multi) {
         __syncthreads();
-        for (int i = lane; i < STATE_WORDS; i += 64) bestcol[i] = priv[i * U + wl];
+        for (int c = lane; c < SG; c += 64) bestcol[c] = priv[c * U + wl];
         __syncthreads();
       }
     }
@@ -452,15 +456,15 @@ __global__ void __launch_bounds__(64, WPE) k_decide(DevBuffers b, int n, int max
   __syncthreads();
   // commit: adapter = adapter.apply_action(best)
   if (multi) {
-    for (int i = lane; i < STATE_WORDS; i += 64) grec[i] = bestcol[i];
+    for (int c = lane; c < SG; c += 64) grec[c] = bestcol[c];
   } else {
-    for (int i = lane; i < STATE_WORDS; i += 64) grec[i] = priv[i * U + wl];
+    for (int c = lane; c < SG; c += 64) grec[c] = priv[c * U + wl];
   }
   __syncthreads();
   int cur = (meta.rng >> 16) & 1;
   if (new_pos >= (uint32_t)MT_N) {
     new_pos -= MT_N;
-    wave_refill(b, g, cur, priv, lane);   // the used-up block becomes the new "next" block
+    wave_refill(b, g, cur, (MSB_AS_LDS uint32_t*)priv, lane);   // the used-up block becomes the new "next" block
     cur ^= 1;
   }
   if (lane == 0) {

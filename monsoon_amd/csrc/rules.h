@@ -1405,7 +1405,10 @@ struct Engine {
       m.st8(pl(o, P_FLAGS), 3);
       m.st8(pl(o, P_FACTION), o == 0 ? faction0 : faction1);
       uint8_t d[DECK_SIZE];
-      for (int i = 0; i < DECK_SIZE; i++) d[i] = deck[i];
+      for (int i = 0; i < DECK_SIZE; i++) {
+        d[i] = deck[i];
+        if (g_cards[d[i]].int_id < 0) m.st8(H_OBSFAULT, 1);
+      }
       for (int i = DECK_SIZE - 1; i >= 1; i--) {  // random.shuffle(self.deck)
         int j = (int)rng.interval((uint32_t)i);
         uint8_t tmp = d[i];

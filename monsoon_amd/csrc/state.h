@@ -51,7 +51,8 @@ constexpr int H_DEPTH = 6;      // recursion guard (build limit)
 constexpr int H_CP = 7;         // order of board.current_player
 constexpr int H_HIST = 8;       // 4 x {owner, card}; oldest first
 constexpr int H_USED = 16;      // u32: entity slots referenced since the start of this step
-constexpr int H_STEPS = 20;     // u16 committed decisions so far (rollout bookkeeping), u16 pad
+constexpr int H_STEPS = 20;     // u16 (reserved)
+constexpr int H_OBSFAULT = 22;  // 1 if a deck holds up01/up02/up03: only then can get_observation raise (card.py:46)
 constexpr int OFF_BOARD = 24;   // 20 x u8 slot
 constexpr int OFF_TRIG = 44;    // TRIG_CAP x u8 (slot | has_source<<7)
 constexpr int OFF_PL = 64;
@@ -104,7 +105,7 @@ constexpr int E_PATH = (E_DMG + 2 * NUM_ENT + 3) & ~3;  // u32 packed path (PATH
 constexpr int E_REM = E_PATH + 4 * NUM_ENT;                       // u8[NUM_ENT]: b005's list id (REM_NONE = [])
 constexpr int OFF_REM = (E_REM + (REM_LISTS ? NUM_ENT : 0) + 3) & ~3; // REM_LISTS x {n, used, pad2, REM_PER_LIST x REM_REC}
 constexpr int REM_LIST_BYTES = 4 + REM_PER_LIST * REM_REC;
-constexpr int STATE_BYTES = (OFF_REM + REM_LISTS * REM_LIST_BYTES + 7) & ~7;
+constexpr int STATE_BYTES = (OFF_REM + REM_LISTS * REM_LIST_BYTES + 15) & ~15;   // whole 16-byte granules
 constexpr int STATE_WORDS = STATE_BYTES / 4;
 constexpr int EF_OWNER = 1, EF_FF = 2, EF_RESOLVING_PLAY = 4, EF_SINGLE_USE = 8;
 
@@ -153,28 +154,22 @@ struct StridedMem {
 // global_load/global_store (HBM) instead of flat_* instructions behind non-inlined calls.
 #define MSB_AS_LDS __attribute__((address_space(3)))
 #define MSB_AS_GLB __attribute__((address_space(1)))
+// LDS image of one record, interleaved across the lanes of a wave in 16-BYTE granules: granule c of
+// lane l sits at (c*LANES + l)*16.  A lane's record is copied 16 bytes at a time (ds_read_b128 /
+// ds_write_b128, conflict-free: consecutive lanes touch consecutive 16-byte slots), f64 weights are one
+// ds_read_b64, and with 8 lanes per game a same-field access by all lanes still hits 8 distinct banks.
 struct LdsMem {
-  MSB_AS_LDS uint32_t* base;   // this lane's column
-  int stride;                  // lanes per wave sharing the block
-  MSB_HD MSB_INL MSB_AS_LDS uint8_t* b(int o) const { return (MSB_AS_LDS uint8_t*)(base + (o >> 2) * stride) + (o & 3); }
+  MSB_AS_LDS uint8_t* base;    // this lane's granule 0
+  int stride;                  // bytes between consecutive granules of one lane (= lanes * 16)
+  MSB_HD MSB_INL MSB_AS_LDS uint8_t* b(int o) const { return base + (o >> 4) * stride + (o & 15); }
   MSB_HD MSB_INL int ld8(int o) const { return *b(o); }
   MSB_HD MSB_INL void st8(int o, int v) { *b(o) = (uint8_t)v; }
   MSB_HD MSB_INL int ld16(int o) const { return *(MSB_AS_LDS const int16_t*)b(o); }
   MSB_HD MSB_INL void st16(int o, int v) { *(MSB_AS_LDS int16_t*)b(o) = (int16_t)v; }
-  MSB_HD MSB_INL uint32_t ld32(int o) const { return base[(o >> 2) * stride]; }
-  MSB_HD MSB_INL void st32(int o, uint32_t v) { base[(o >> 2) * stride] = v; }
-  MSB_HD MSB_INL double ldf(int o) const {
-    union { uint32_t u[2]; double d; } x;
-    x.u[0] = ld32(o);
-    x.u[1] = ld32(o + 4);
-    return x.d;
-  }
-  MSB_HD MSB_INL void stf(int o, double v) {
-    union { uint32_t u[2]; double d; } x;
-    x.d = v;
-    st32(o, x.u[0]);
-    st32(o + 4, x.u[1]);
-  }
+  MSB_HD MSB_INL uint32_t ld32(int o) const { return *(MSB_AS_LDS const uint32_t*)b(o); }
+  MSB_HD MSB_INL void st32(int o, uint32_t v) { *(MSB_AS_LDS uint32_t*)b(o) = v; }
+  MSB_HD MSB_INL double ldf(int o) const { return *(MSB_AS_LDS const double*)b(o); }
+  MSB_HD MSB_INL void stf(int o, double v) { *(MSB_AS_LDS double*)b(o) = v; }
 };
 #endif
 

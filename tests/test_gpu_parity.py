@@ -20,10 +20,10 @@ def engines():
     from monsoon_amd.engine import BatchEngine
     cache = {}
 
-    def get(n, lanes=0):
-        key = (n, lanes)
+    def get(n, lanes=0, extended=False):
+        key = (n, lanes, extended)
         if key not in cache:
-            cache[key] = BatchEngine(n, lanes_per_game=lanes)
+            cache[key] = BatchEngine(n, lanes_per_game=lanes, extended=extended)
         return cache[key]
     yield get
     for e in cache.values():
@@ -32,26 +32,30 @@ def engines():
 
 def test_initial_states_vs_reference(engines, gold):
     g = gold("initial_states.npz")
-    ok = [k for k in range(len(g["seeds"])) if k < 10]   # N12V, N12M (S12 holds s203: unsupported, refused)
+    ok = list(range(len(g["seeds"])))   # N12V, N12M, S12
     eng = engines(16)
     eng.reset(g["seeds"][ok].astype(np.uint32), np.stack([np.stack([g["decks"][k]] * 2) for k in ok]))
     for j, k in enumerate(ok):
         assert eng.export(j) == g["canon"][k][:g["length"][k]].tobytes(), k
 
 
-@pytest.mark.parametrize("name", ["trace_random_N12V.npz", "trace_random_N12M.npz", "trace_random_IRONCLAD.npz", "trace_pool.npz"])
+@pytest.mark.parametrize("name", ["trace_random_N12V.npz", "trace_random_N12M.npz", "trace_random_IRONCLAD.npz",
+                                  "trace_random_S12.npz", "trace_pool.npz", "trace_pool_ext.npz"])
 def test_random_policy_traces_vs_reference(engines, gold, name):
-    """Replays the reference's seeded random-policy games through monsoon_step in lockstep."""
+    """Replays the reference's seeded random-policy games through monsoon_step in lockstep
+    (trace_pool_ext: all 109 observable cards on the extended-record build)."""
     g = gold(name)
     n = len(g["seeds"])
-    eng = engines(256)
+    ext = name.endswith("_ext.npz")
+    eng = engines(256, 0, ext)
     eng.reset(g["seeds"], np.stack([g["deck0"], g["deck1"]], axis=1))
     assert np.array_equal(eng.state_hash(), g["init_hash"])
-    orc = oracle_lib.Oracle(n)
+    orc = oracle_lib.Oracle(n, extended=ext)
     for k in range(n):
         orc.reset(k, int(g["seeds"][k]), g["deck0"][k], g["deck1"][k])
     off = g["offsets"]
-    lens = off[1:] - off[:-1]
+    lens = (off[1:] - off[:-1]).copy()
+    unsupported = 0
     for t in range(int(lens.max())):
         live = np.nonzero(lens > t)[0]
         masks = eng.legal_mask()
@@ -68,10 +72,15 @@ def test_random_policy_traces_vs_reference(engines, gold, name):
             if g["fault"][k] and t == lens[k] - 1:   # the reference raised on this step
                 assert fault[k] != 0 or raises[k], (k, t)
                 continue
+            if ext and fault[k] == 20 and fo == 20:   # FAULT_UNSUPPORTED (nested b005 memory): flagged on both builds
+                lens[k] = t + 1
+                unsupported += 1
+                continue
             assert fault[k] == 0 and fo == 0, (k, t, fault[k])
             assert hashes[k] == g["hash"][i], (k, t)
             assert (reward[k], done[k]) == (g["reward"][i], g["done"][i]), (k, t)
             assert np.array_equal(obs[k], orc.observe(k)), (k, t)
+    assert unsupported <= 0.05 * n
     if "feat" in g.files:
         feat = eng.features()
         for k in range(n):
@@ -192,7 +201,9 @@ def test_game_view_and_error_behaviour(engines):
     e = BatchEngine(4)
     with pytest.raises(MonsoonError, match="monsoon_reset first"):
         e.legal_mask()
-    bad = np.stack([deck_indices("S12"), deck_indices("S12")])
+    ua20_deck = deck_indices("N12M").copy()
+    ua20_deck[0] = __import__("monsoon_amd").CARD_INDEX["ua20"]   # needs the extended record
+    bad = np.stack([ua20_deck, ua20_deck])
     with pytest.raises(MonsoonError, match="not supported"):
         e.reset(np.array([1], dtype=np.uint32), bad[None])
     e.close()

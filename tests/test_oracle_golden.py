@@ -46,13 +46,15 @@ def test_initial_states(oracle_mod, gold):
     orc = oracle_mod.Oracle(1)
     for k in range(len(g["seeds"])):
         deck = g["decks"][k]
-        # S12 contains s203, which this build does not restate yet: construction itself is covered
         f = orc.reset(0, int(g["seeds"][k]), deck, deck)
         assert f == 0
         assert orc.canon(0) == g["canon"][k][:g["length"][k]].tobytes(), k
 
 
-def _replay(orc, g, k, check_feat=False):
+FAULT_UNSUPPORTED = 20   # msb_base.h: behaviour the record cannot express (nested b005 memories)
+
+
+def _replay(orc, g, k, check_feat=False, unsupported=None):
     lo, hi = int(g["offsets"][k]), int(g["offsets"][k + 1])
     assert orc.reset(0, int(g["seeds"][k]), g["deck0"][k], g["deck1"][k]) == 0
     assert orc.canon_hash(0) == int(g["init_hash"][k])
@@ -63,6 +65,9 @@ def _replay(orc, g, k, check_feat=False):
         if last_faulted:
             assert f != 0 or orc.observe(0) is None, (k, t)
             break
+        if f == FAULT_UNSUPPORTED and unsupported is not None:
+            unsupported.append(k)   # flagged, never silent: the game stops here instead of diverging
+            return t - lo
         assert f == 0, (k, t, f)
         assert orc.canon_hash(0) == int(g["hash"][t]), (k, t)
         assert orc.obs_hash(0) == int(g["obs"][t]), (k, t)
@@ -73,12 +78,39 @@ def _replay(orc, g, k, check_feat=False):
 
 
 @pytest.mark.parametrize("name,feat", [("trace_random_N12V.npz", False), ("trace_random_N12M.npz", True),
-                                       ("trace_random_IRONCLAD.npz", False), ("trace_pool.npz", False)])
+                                       ("trace_random_IRONCLAD.npz", False), ("trace_random_S12.npz", False),
+                                       ("trace_pool.npz", False)])
 def test_random_policy_traces(oracle_mod, gold, name, feat):
     g = gold(name)
     orc = oracle_mod.Oracle(1)
     steps = sum(_replay(orc, g, k, feat) for k in range(len(g["seeds"])))
     assert steps == len(g["action"])
+
+
+def test_extended_record_pool_traces(oracle_mod, gold):
+    """All 109 observable cards (ua20, b005 included) on the extended build.  The one behaviour the
+    record cannot express -- restoring a NESTED b005 memory, whose entities live on a deep-copied
+    phantom board in the reference -- must surface as FAULT_UNSUPPORTED, and stay rare."""
+    g = gold("trace_pool_ext.npz")
+    orc = oracle_mod.Oracle(1, extended=True)
+    unsupported = []
+    steps = sum(_replay(orc, g, k, False, unsupported) for k in range(len(g["seeds"])))
+    assert steps > 0.9 * len(g["action"])
+    assert len(unsupported) <= 0.05 * len(g["seeds"]), unsupported
+
+
+def test_set_iteration_order_known_answers(oracle_mod):
+    """cards/s203.py iterates a set of Points: CPython's insertion/probing order, restated in pyset.h."""
+    import ctypes
+    import json
+    import os
+    from conftest import GOLD
+    L = oracle_mod.lib()
+    for idx, exp in json.load(open(os.path.join(GOLD, "set_order_kat.json"))):
+        k = np.array(idx, dtype=np.uint8)
+        out = np.zeros(32, dtype=np.uint8)
+        m = L.orc_pyset_list(_p(k), len(idx), _p(out))
+        assert list(out[:m]) == exp
 
 
 def test_heuristic_selfplay_trace(oracle_mod, gold):
