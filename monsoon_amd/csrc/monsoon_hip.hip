@@ -112,7 +112,7 @@ __device__ void wave_refill(const DevBuffers& b, int g, int which, MSB_AS_LDS ui
 }
 
 __device__ MSB_INL RngView make_view(const DevBuffers& b, int g, uint32_t rng) {
-  const uint32_t* base = b.rng_out + (size_t)g * RNG_WORDS;
+  MSB_RNG_PTR base = (MSB_RNG_PTR)(b.rng_out + (size_t)g * RNG_WORDS);
   int cur = (rng >> 16) & 1;
   return RngView{base + cur * MT_N, base + (cur ^ 1) * MT_N, rng & 0xffffu, 0};
 }
@@ -379,8 +379,8 @@ __global__ void __launch_bounds__(64, WPE) k_decide(DevBuffers b, int n, int max
     return;
   }
 
-  uint64_t mask[3];
-  pe.legal_mask(mask);
+  const msb_u64x4 lm = pe.legal_mask_v();
+  const uint64_t mask[3] = {lm[0], lm[1], lm[2]};
   const int n_legal = __popcll(mask[0]) + __popcll(mask[1]) + __popcll(mask[2]);
   const bool before_raises = pe.observation_raises();
   double fb[10];

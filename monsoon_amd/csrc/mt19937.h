@@ -53,9 +53,14 @@ MSB_HD inline void mt_twist(uint32_t* mt) {
 // private cursor (the reference's copy.deepcopy clones the stream, evo/game_adapter.py:284), so
 // many candidate steps of one decision read the same window.  Consuming more than the window
 // sets `overrun` (FAULT_RNG_OVERRUN): a single step would have to draw > 624 words.
+#if defined(__HIPCC__)
+#define MSB_RNG_PTR __attribute__((address_space(1))) const uint32_t*   // global_load, not flat_load
+#else
+#define MSB_RNG_PTR const uint32_t*
+#endif
 struct RngView {
-  const uint32_t* cur;
-  const uint32_t* nxt;
+  MSB_RNG_PTR cur;
+  MSB_RNG_PTR nxt;
   uint32_t pos;      // index of the next word, 0..1247 (>= 624 reads nxt)
   uint32_t overrun;
 

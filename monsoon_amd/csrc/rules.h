@@ -29,39 +29,86 @@ MSB_HD MSB_INL int p_tile(P p) { return p.y * 4 + p.x; }
 MSB_HD MSB_INL P tile_p(int t) { return P{t & 3, t >> 2}; }
 constexpr int PK_NONE = 0xFF;
 
+// Point lists (results of the selectors: at most 20 tiles + 2 bases) live in REGISTERS: 24 six-bit
+// packed points in three 64-bit lanes of a 4 x u64 vector, the length in the fourth.  A vector type is
+// passed to and returned from the non-inlined selector functions in VGPRs; a byte array would sit in
+// the per-lane scratch stack and every access would be a global-memory round trip (the round-1 profile
+// showed 72 % of the wave cycles waiting on exactly that).
+typedef unsigned long long msb_u64x4 __attribute__((vector_size(32)));   // <4 x i64>: GCC and clang spelling
 struct PList {
-  int n;
-  uint8_t v[24];
-  MSB_HD MSB_INL void clear() { n = 0; }
-  MSB_HD MSB_INL void push(P p) {
-    if (n < 24) v[n++] = (uint8_t)p_pack(p);
+  msb_u64x4 w;
+  MSB_HD MSB_INL int n() const { return (int)w[3]; }
+  MSB_HD MSB_INL void set_n(int k) { w[3] = (unsigned long long)k; }
+  MSB_HD MSB_INL void clear() { w = msb_u64x4{0ull, 0ull, 0ull, 0ull}; }
+  MSB_HD MSB_INL int get(int i) const {   // packed point at index i
+    unsigned long long x = i < 10 ? w[0] : (i < 20 ? w[1] : w[2]);
+    int k = i < 10 ? i : (i < 20 ? i - 10 : i - 20);
+    return (int)((x >> (6 * k)) & 63ull);
   }
-  MSB_HD MSB_INL P at(int i) const { return p_unpack(v[i]); }
+  MSB_HD MSB_INL void set(int i, int v) {
+    int k = i < 10 ? i : (i < 20 ? i - 10 : i - 20);
+    unsigned long long msk = ~(63ull << (6 * k)), bits = (unsigned long long)(v & 63) << (6 * k);
+    if (i < 10)
+      w[0] = (w[0] & msk) | bits;
+    else if (i < 20)
+      w[1] = (w[1] & msk) | bits;
+    else
+      w[2] = (w[2] & msk) | bits;
+  }
+  MSB_HD MSB_INL void push_raw(int v) {
+    int i = n();
+    if (i < 24) {
+      set(i, v);
+      set_n(i + 1);
+    }
+  }
+  MSB_HD MSB_INL void push(P p) { push_raw(p_pack(p)); }
+  MSB_HD MSB_INL P at(int i) const { return p_unpack(get(i)); }
   MSB_HD MSB_INL bool has(P p) const {
-    int k = p_pack(p);
-    for (int i = 0; i < n; i++)
-      if (v[i] == k) return true;
+    int k = p_pack(p), m = n();
+    for (int i = 0; i < m; i++)
+      if (get(i) == k) return true;
     return false;
   }
   MSB_HD MSB_INL void remove_at(int i) {
-    for (int j = i; j + 1 < n; j++) v[j] = v[j + 1];
-    n--;
+    int m = n();
+    for (int j = i; j + 1 < m; j++) set(j, get(j + 1));
+    set_n(m - 1);
   }
 };
 
-// Target descriptor (target.py:18-29)
-struct Tgt {
-  int kind, side;
-  int types, xtypes;   // UnitType masks, 0 = None
-  int limit;           // strength_limit, LIMIT_NONE = None
-  int non_hero;
-  int status, xstatus; // StatusEffect masks, 0 = None
-  int base;            // include_base
-};
+// Target descriptor (target.py:18-29) packed into one 64-bit scalar (passed in registers):
+//   kind 0-1 | side 2-3 | non_hero 4 | base 5 | status 6-10 | xstatus 11-15 | types 16-31 | xtypes 32-47 |
+//   limit+32768 48-63 (0 = None)
+typedef unsigned long long Tgt;
 constexpr int LIMIT_NONE = -32768;
-MSB_HD MSB_INL Tgt mk_tgt(int kind, int side) { return Tgt{kind, side, 0, 0, LIMIT_NONE, 0, 0, 0, 0}; }
+MSB_HD MSB_INL Tgt mk_tgt(int kind, int side) { return (Tgt)kind | ((Tgt)side << 2); }
+MSB_HD MSB_INL Tgt tgt_types(Tgt t, int types) { return t | ((Tgt)(types & 0xffff) << 16); }
+MSB_HD MSB_INL Tgt tgt_xtypes(Tgt t, int xtypes) { return t | ((Tgt)(xtypes & 0xffff) << 32); }
+MSB_HD MSB_INL Tgt tgt_status(Tgt t, int status) { return t | ((Tgt)(status & 31) << 6); }
+MSB_HD MSB_INL Tgt tgt_xstatus(Tgt t, int xstatus) { return t | ((Tgt)(xstatus & 31) << 11); }
+MSB_HD MSB_INL Tgt tgt_base(Tgt t) { return t | (1ull << 5); }
+MSB_HD MSB_INL Tgt tgt_non_hero(Tgt t) { return t | (1ull << 4); }
+MSB_HD MSB_INL Tgt tgt_limit(Tgt t, int limit) { return (t & 0x0000ffffffffffffull) | ((Tgt)((limit + 32768) & 0xffff) << 48); }
+MSB_HD MSB_INL int tg_kind(Tgt t) { return (int)(t & 3); }
+MSB_HD MSB_INL int tg_side(Tgt t) { return (int)((t >> 2) & 3); }
+MSB_HD MSB_INL bool tg_non_hero(Tgt t) { return (t >> 4) & 1; }
+MSB_HD MSB_INL bool tg_base(Tgt t) { return (t >> 5) & 1; }
+MSB_HD MSB_INL int tg_status(Tgt t) { return (int)((t >> 6) & 31); }
+MSB_HD MSB_INL int tg_xstatus(Tgt t) { return (int)((t >> 11) & 31); }
+MSB_HD MSB_INL int tg_types(Tgt t) { return (int)((t >> 16) & 0xffff); }
+MSB_HD MSB_INL int tg_xtypes(Tgt t) { return (int)((t >> 32) & 0xffff); }
+MSB_HD MSB_INL int tg_limit(Tgt t) { return (int)((t >> 48) & 0xffff) - 32768; }   // LIMIT_NONE when unset
 MSB_HD MSB_INL Tgt mk_tgt(const TargetSpec& s) {
-  return Tgt{s.kind, s.side, s.types, s.xtypes, s.limit < 0 ? LIMIT_NONE : s.limit, s.non_hero, s.status, s.xstatus, s.base};
+  Tgt t = mk_tgt(s.kind, s.side);
+  t = tgt_types(t, s.types);
+  t = tgt_xtypes(t, s.xtypes);
+  if (s.limit >= 0) t = tgt_limit(t, s.limit);
+  if (s.non_hero) t = tgt_non_hero(t);
+  t = tgt_status(t, s.status);
+  t = tgt_xstatus(t, s.xstatus);
+  if (s.base) t = tgt_base(t);
+  return t;
 }
 
 // Results of Board.at (board.py:58-65)
@@ -489,9 +536,12 @@ struct Engine {
   MSB_HD MSB_INL void recalc_front_after_destroy() { calculate_front_line(opponent_of(cp())); }
 
   // Board.get_targets, board.py:147-204
-  MSB_HD MSB_NOINLINE void get_targets(PList& out, int pov, const Tgt& t, int exclude_pk) {
+  MSB_HD MSB_NOINLINE PList get_targets(int pov, Tgt t, int exclude_pk) {
+    PList out;
     out.clear();
-    bool asc = (pov == local());
+    const bool asc = (pov == local());
+    const int kind = tg_kind(t), side = tg_side(t), limit = tg_limit(t);
+    const int types = tg_types(t), xtypes = tg_xtypes(t), status = tg_status(t), xstatus = tg_xstatus(t);
     for (int i = 0; i < 20; i++) {
       int tile = asc ? i : 19 - i;
       int e = board_at(tile);
@@ -500,41 +550,43 @@ struct Engine {
       if (str <= 0) continue;
       int c = e_card(e);
       bool is_unit = card_is_unit(c);
-      bool strength_ok = t.limit == LIMIT_NONE || str <= t.limit;
+      bool strength_ok = limit == LIMIT_NONE || str <= limit;
       bool ok;
       if (is_unit) {
         int ty = card_types(c);
-        bool type_ok = t.types == 0 || (ty & t.types) != 0;
-        bool xtype_ok = t.xtypes == 0 || (ty & t.xtypes) == 0;
-        bool hero_ok = !t.non_hero || !(ty & (1 << UT_HERO));
+        bool type_ok = types == 0 || (ty & types) != 0;
+        bool xtype_ok = xtypes == 0 || (ty & xtypes) == 0;
+        bool hero_ok = !tg_non_hero(t) || !(ty & (1 << UT_HERO));
         int stm = 0;
-        if (t.status | t.xstatus)
+        if (status | xstatus)
           for (int s = 0; s < 5; s++)
             if (e_st(e, s) > 0) stm |= 1 << s;
-        bool st_ok = t.status == 0 || (stm & t.status) != 0;
-        bool xst_ok = t.xstatus == 0 || (stm & t.xstatus) == 0;
-        ok = type_ok && xtype_ok && hero_ok && st_ok && xst_ok && strength_ok && (t.kind == TK_ANY || t.kind == TK_UNIT);
+        bool st_ok = status == 0 || (stm & status) != 0;
+        bool xst_ok = xstatus == 0 || (stm & xstatus) == 0;
+        ok = type_ok && xtype_ok && hero_ok && st_ok && xst_ok && strength_ok && (kind == TK_ANY || kind == TK_UNIT);
       } else {
-        ok = strength_ok && (t.kind == TK_ANY || t.kind == TK_STRUCTURE);
+        ok = strength_ok && (kind == TK_ANY || kind == TK_STRUCTURE);
       }
       if (!ok) continue;
       int own = e_owner(e);
-      bool side_ok = t.side == TS_ANY || (t.side == TS_FRIENDLY && own == pov) || (t.side == TS_ENEMY && own != pov);
+      bool side_ok = side == TS_ANY || (side == TS_FRIENDLY && own == pov) || (side == TS_ENEMY && own != pov);
       if (side_ok) out.push(tile_p(tile));
     }
-    if (t.base) {
+    if (tg_base(t)) {
       P friendly = asc ? P{-1, 5} : P{-1, -1};
       P enemy = asc ? P{-1, -1} : P{-1, 5};
-      if (t.side == TS_FRIENDLY || t.side == TS_ANY) out.push(friendly);
-      if (t.side == TS_ENEMY || t.side == TS_ANY) out.push(enemy);
+      if (side == TS_FRIENDLY || side == TS_ANY) out.push(friendly);
+      if (side == TS_ENEMY || side == TS_ANY) out.push(enemy);
     }
     if (exclude_pk != PK_NONE) {
-      for (int i = 0; i < out.n; i++)
-        if (out.v[i] == exclude_pk) {
+      int m = out.n();
+      for (int i = 0; i < m; i++)
+        if (out.get(i) == exclude_pk) {
           out.remove_at(i);
           break;
         }
     }
+    return out;
   }
 
   // membership of `p` in the raw tile list of a geometric selector (board.py:206-296)
@@ -551,7 +603,8 @@ struct Engine {
     }
   }
   // get_front_tiles .. get_surrounding_tiles WITHOUT a target: fixed enumeration order.
-  MSB_HD MSB_NOINLINE void shape_tiles(PList& out, int shape, P c, int pov) {
+  MSB_HD MSB_NOINLINE PList shape_tiles(int shape, P c, int pov) {
+    PList out;
     out.clear();
     switch (shape) {
       case SH_FRONT:
@@ -600,72 +653,79 @@ struct Engine {
         }
       } break;
     }
+    return out;
   }
   // ... WITH a target: get_targets order filtered by membership; front/behind re-sorted by y.
-  MSB_HD MSB_NOINLINE void shape_targets(PList& out, int shape, P c, int pov, const Tgt& t, int exclude_pk) {
-    PList all;
-    get_targets(all, pov, t, exclude_pk);
+  MSB_HD MSB_NOINLINE PList shape_targets(int shape, P c, int pov, Tgt t, int exclude_pk) {
+    PList all = get_targets(pov, t, exclude_pk);
+    PList out;
     out.clear();
     bool base_rule = (shape == SH_FRONT || shape == SH_BEHIND || shape == SH_COLUMN || shape == SH_BORDERING ||
                       shape == SH_SURROUNDING);
-    for (int i = 0; i < all.n; i++) {
+    int m = all.n();
+    for (int i = 0; i < m; i++) {
       P p = all.at(i);
-      if (in_shape(shape, c, pov, p) || (base_rule && p_is_base(p) && t.base)) out.v[out.n++] = all.v[i];
+      if (in_shape(shape, c, pov, p) || (base_rule && p_is_base(p) && tg_base(t))) out.push_raw(all.get(i));
     }
     if (shape == SH_FRONT || shape == SH_BEHIND) {
       // stable sort by y; reverse=True keeps equal keys in original order too (CPython list.sort)
       bool desc = (shape == SH_FRONT) ? (pov == local()) : (pov == remote());
-      for (int i = 1; i < out.n; i++) {
-        uint8_t k = out.v[i];
+      int on = out.n();
+      for (int i = 1; i < on; i++) {
+        int k = out.get(i);
         int ky = p_unpack(k).y;
         int j = i - 1;
-        while (j >= 0 && (desc ? p_unpack(out.v[j]).y < ky : p_unpack(out.v[j]).y > ky)) {
-          out.v[j + 1] = out.v[j];
+        while (j >= 0 && (desc ? p_unpack(out.get(j)).y < ky : p_unpack(out.get(j)).y > ky)) {
+          out.set(j + 1, out.get(j));
           j--;
         }
-        out.v[j + 1] = k;
+        out.set(j + 1, k);
       }
     }
+    return out;
   }
 
   // numpy RandomState.choice(list) / shuffle(list)
   MSB_HD MSB_INL int choice_index(int n) { return rng.randint(0, n); }
-  MSB_HD MSB_INL P choice_point(const PList& l) { return l.at(choice_index(l.n)); }
-  MSB_HD MSB_NOINLINE void shuffle(PList& l) {
-    for (int i = l.n - 1; i >= 1; i--) {
+  MSB_HD MSB_INL P choice_point(PList l) { return l.at(choice_index(l.n())); }
+  MSB_HD MSB_NOINLINE PList shuffle(PList l) {
+    for (int i = l.n() - 1; i >= 1; i--) {
       int j = (int)rng.interval((uint32_t)i);
-      uint8_t tmp = l.v[i];
-      l.v[i] = l.v[j];
-      l.v[j] = tmp;
+      int tmp = l.get(i);
+      l.set(i, l.get(j));
+      l.set(j, tmp);
     }
+    return l;
   }
-  // list.sort(key=lambda t: (key(t), random.random()), reverse=rev): random() is called once per
-  // element in list order before sorting; the sort is stable, reverse keeps ties in order.
-  MSB_HD MSB_NOINLINE void sort_by_key_random(PList& l, const int* key, bool rev) {
-    double r[24];
-    int k[24];
-    for (int i = 0; i < l.n; i++) {
-      k[i] = key[i];
-      r[i] = rng.random_sample();
-    }
-    for (int i = 1; i < l.n; i++) {
-      uint8_t pv = l.v[i];
-      int kv = k[i];
-      double rv = r[i];
-      int j = i - 1;
-      while (j >= 0) {
-        bool less = (kv < k[j]) || (kv == k[j] && rv < r[j]);
-        bool greater = (kv > k[j]) || (kv == k[j] && rv > r[j]);
-        if (rev ? !greater : !less) break;
-        l.v[j + 1] = l.v[j];
-        k[j + 1] = k[j];
-        r[j + 1] = r[j];
-        j--;
+  // targets.sort(key=lambda t: (key(t), random.random()), reverse=rev)[:k] for k <= 2, the only uses the
+  // cards make of it (b002 b008 b009 b104 s101).  random() is called once per element in list order
+  // BEFORE sorting; the sort is stable and reverse keeps ties in order, so the first k of the sorted
+  // list are the k best under (key, r) with earlier elements winning ties.  key_mode: 0 = y, 1 = strength.
+  MSB_HD MSB_NOINLINE PList sorted_head(PList l, int key_mode, bool rev, int k) {
+    int b0 = -1, b1 = -1, k0 = 0, k1 = 0;
+    double r0 = 0.0, r1 = 0.0;
+    int m = l.n();
+    for (int i = 0; i < m; i++) {
+      P p = l.at(i);
+      int kv = key_mode == 0 ? p.y : e_str(at(p));
+      double rv = rng.random_sample();
+      // does element i sort strictly before the current best / second best?
+      bool lt0 = b0 < 0 || (rev ? (kv > k0 || (kv == k0 && rv > r0)) : (kv < k0 || (kv == k0 && rv < r0)));
+      if (lt0) {
+        b1 = b0; k1 = k0; r1 = r0;
+        b0 = i; k0 = kv; r0 = rv;
+      } else {
+        bool lt1 = b1 < 0 || (rev ? (kv > k1 || (kv == k1 && rv > r1)) : (kv < k1 || (kv == k1 && rv < r1)));
+        if (lt1) {
+          b1 = i; k1 = kv; r1 = rv;
+        }
       }
-      l.v[j + 1] = pv;
-      k[j + 1] = kv;
-      r[j + 1] = rv;
     }
+    PList out;
+    out.clear();
+    if (b0 >= 0 && k >= 1) out.push_raw(l.get(b0));
+    if (b1 >= 0 && k >= 2) out.push_raw(l.get(b1));
+    return out;
   }
 
   // ------------------------------------------------------------------------------------------
@@ -824,7 +884,7 @@ struct Engine {
     int steps = on_play ? e_mov(e) : 1;
     uint32_t packed = 0;
     int n = 0;
-    uint8_t dests[8];
+    unsigned long long dests = 0;   // up to 8 packed destinations, one byte each (kept in registers)
     int nd = 0;
     for (int k = 0; k < steps; k++) {
       P dest{position.x, position.y + (is_local ? -1 : 1)};
@@ -849,8 +909,9 @@ struct Engine {
         int lpk = p_pack(lp), rpk = p_pack(rp);
         bool lseen = false, rseen = false;
         for (int i = 0; i < nd; i++) {
-          if (dests[i] == lpk) lseen = true;
-          if (dests[i] == rpk) rseen = true;
+          int dv = (int)((dests >> (8 * i)) & 0xff);
+          if (dv == lpk) lseen = true;
+          if (dv == rpk) rseen = true;
         }
         if (position.x <= 1) {
           if (right_ok && !rseen)
@@ -869,7 +930,7 @@ struct Engine {
       P enc = dest;
       if (enc.y < -1) enc.y = -1;
       if (enc.y > 5) enc.y = 5;
-      if (nd < 8) dests[nd++] = (uint8_t)p_pack(enc);
+      if (nd < 8) dests |= (unsigned long long)p_pack(enc) << (8 * nd++);
       if (n < PATH_CAP) {
         packed |= (uint32_t)p_pack(enc) << (8 * n);
         n++;
@@ -1121,18 +1182,21 @@ struct Engine {
       }
       double sum = 0.0;  // Python sum(): 0 + w0 + w1 ... left to right
       for (int i = 0; i < n; i++) sum = sum + deck_w(o, i);
-      double cdf[DECK_CAP];
-      double acc = 0.0;
+      // cdf = cumsum(w/sum); cdf /= cdf[-1]; idx = searchsorted(cdf, u, 'right').  The running sum is
+      // recomputed in the second pass (same operations, same order) instead of being kept in an array.
+      double last = 0.0;
       for (int i = 0; i < n; i++) {
         double p = deck_w(o, i) / sum;
-        acc = (i == 0) ? p : acc + p;   // ndarray.cumsum: sequential
-        cdf[i] = acc;
+        last = (i == 0) ? p : last + p;   // ndarray.cumsum: sequential
       }
-      double last = cdf[n - 1];
-      for (int i = 0; i < n; i++) cdf[i] = cdf[i] / last;
       double u = rng.random_sample();
-      int idx = 0;  // searchsorted(side='right')
-      while (idx < n && cdf[idx] <= u) idx++;
+      int idx = 0;
+      double acc = 0.0;
+      for (; idx < n; idx++) {
+        double p = deck_w(o, idx) / sum;
+        acc = (idx == 0) ? p : acc + p;
+        if (!(acc / last <= u)) break;
+      }
       if (idx >= n) {
         set_fault(FAULT_PY_EXCEPTION);
         return;
@@ -1207,11 +1271,10 @@ struct Engine {
       bool go = true;
       if (ci.tgt.has) {
         Tgt t = mk_tgt(ci.tgt);
-        PList l;
-        get_targets(l, cp(), t, PK_NONE);
+        PList l = get_targets(cp(), t, PK_NONE);
         go = has_pos && l.has(position);
         // `None in [Point...]` evaluates Point.__eq__(None) -> AttributeError when the list is non-empty
-        if (!has_pos && l.n > 0) {
+        if (!has_pos && l.n() > 0) {
           set_fault(FAULT_PY_EXCEPTION);
           return;
         }
@@ -1261,29 +1324,23 @@ struct Engine {
     int ncp = (ender == local()) ? remote() : local();
     m.st8(H_CP, ncp);
     m.st8(pl(ncp, P_FLAGS), m.ld8(pl(ncp, P_FLAGS)) | 3);
-    // snapshots of entity objects (fact #6)
-    uint8_t snap[20];
-    int ns = 0;
-    {
-      PList l;
-      get_targets(l, ncp, mk_tgt(TK_STRUCTURE, TS_FRIENDLY), PK_NONE);
-      for (int i = 0; i < l.n; i++) snap[ns++] = (uint8_t)at(l.at(i));
-    }
+    // snapshots of entity objects (fact #6): the same packed list type holds the slot ids (< 64)
+    PList snap = get_targets(ncp, mk_tgt(TK_STRUCTURE, TS_FRIENDLY), PK_NONE);
+    int ns = snap.n();
+    for (int i = 0; i < ns; i++) snap.set(i, at(snap.at(i)));
     for (int i = 0; i < ns; i++) {
-      int s = snap[i];
+      int s = snap.get(i);
       // structure.is_at_turn_start: token structures and b001 run the empty base ability
       if (card_trigger(e_card(s)) == TR_TURN_START) run_ability(s, -1, m.ld8(E_POS + s) /*unused*/, true);
       if (fault()) return;
     }
-    ns = 0;
-    {
-      PList l;
-      get_targets(l, ncp, mk_tgt(TK_UNIT, TS_FRIENDLY), PK_NONE);
-      for (int i = 0; i < l.n; i++) snap[ns++] = (uint8_t)at(l.at(i));
-    }
+    snap = get_targets(ncp, mk_tgt(TK_UNIT, TS_FRIENDLY), PK_NONE);
+    ns = snap.n();
+    for (int i = 0; i < ns; i++) snap.set(i, at(snap.at(i)));
     for (int i = 0; i < ns; i++) {
-      set_path(snap[i], false);
-      move(snap[i]);
+      int u = snap.get(i);
+      set_path(u, false);
+      move(u);
       if (fault()) return;
     }
     m.st8(H_PHASE, PH_PLAY);
@@ -1293,11 +1350,19 @@ struct Engine {
   MSB_HD MSB_INL bool have_winner() const { return pl_base(0) < 0 || pl_base(1) < 0; }
 
   // Stormbound.legal_actions + Action.to_int, games/stormbound.py:528-557, 258-290 -> 156-bit mask
-  MSB_HD MSB_NOINLINE void legal_mask(uint64_t mask[3]) {
-    mask[0] = mask[1] = mask[2] = 0;
+  // (three 64-bit words in a register vector)
+  MSB_HD MSB_NOINLINE msb_u64x4 legal_mask_v() {
+    unsigned long long m0 = 0, m1 = 0, m2 = 0;
     int lo = local();
     int hn = pl_hand_n(lo), mana = pl_mana(lo), fl = pl_front(lo);
     bool any_play = false;
+#define MSB_SETBIT(a)                                   \
+  do {                                                  \
+    int a_ = (a);                                       \
+    if (a_ < 64) m0 |= 1ull << a_;                      \
+    else if (a_ < 128) m1 |= 1ull << (a_ - 64);         \
+    else if (a_ < 156) m2 |= 1ull << (a_ - 128);        \
+  } while (0)
     for (int c = 0; c < hn; c++) {
       if (hand_cost(lo, c) > mana) continue;
       int card = hand_card(lo, c);
@@ -1307,32 +1372,33 @@ struct Engine {
           for (int x = 0; x < 4; x++)
             if (board_at(y * 4 + x) == SLOT_NONE) {
               // to_int only enumerates y=4..1; anything else stays 155 (games/stormbound.py:262-271)
-              int a = (y >= 1) ? 16 * c + (4 - y) * 4 + x : 155;
-              if (a < 156) mask[a >> 6] |= 1ull << (a & 63);
+              MSB_SETBIT((y >= 1) ? 16 * c + (4 - y) * 4 + x : 155);
               any_play = true;
             }
       } else if (!ci.tgt.has) {
-        int a = 64 + 21 * c;
-        if (a < 156) mask[a >> 6] |= 1ull << (a & 63);
+        MSB_SETBIT(64 + 21 * c);
         any_play = true;
       } else {
-        Tgt t = mk_tgt(ci.tgt);
-        PList l;
-        get_targets(l, cp(), t, PK_NONE);
-        for (int i = 0; i < l.n; i++) {
+        PList l = get_targets(cp(), mk_tgt(ci.tgt), PK_NONE);
+        int ln = l.n();
+        for (int i = 0; i < ln; i++) {
           P p = l.at(i);
-          int a = p_valid(p) ? 65 + 21 * c + (4 - p.y) * 4 + p.x : 155;
-          if (a < 156) mask[a >> 6] |= 1ull << (a & 63);
+          MSB_SETBIT(p_valid(p) ? 65 + 21 * c + (4 - p.y) * 4 + p.x : 155);
           any_play = true;
         }
       }
     }
     if (m.ld8(pl(lo, P_FLAGS)) & 1)
-      for (int c = 0; c < hn; c++) {
-        int a = 148 + c;
-        mask[a >> 6] |= 1ull << (a & 63);
-      }
-    if (!any_play) mask[2] |= 1ull << (155 & 63);
+      for (int c = 0; c < hn; c++) MSB_SETBIT(148 + c);
+    if (!any_play) MSB_SETBIT(155);
+#undef MSB_SETBIT
+    return msb_u64x4{m0, m1, m2, 0ull};
+  }
+  MSB_HD MSB_INL void legal_mask(uint64_t mask[3]) {
+    msb_u64x4 r = legal_mask_v();
+    mask[0] = r[0];
+    mask[1] = r[1];
+    mask[2] = r[2];
   }
 
   // Stormbound.step, games/stormbound.py:318-373 (without the observation; see features.h).
