@@ -91,6 +91,9 @@ int monsoon_status(monsoon_t* h, int32_t* out);
  * bit-exactness tests.  buf must hold 1024 bytes. */
 int monsoon_state_export(monsoon_t* h, int32_t idx, uint8_t* buf, int32_t* len);
 
+/* Debugging aid: the raw HBM record of game idx (monsoon_amd/csrc/state.h layout); buf must hold 4096 bytes. */
+int monsoon_debug_raw(monsoon_t* h, int32_t idx, uint8_t* buf, int32_t* len);
+
 /* FNV-1a 64 of the canonical record of every game: out[n].  Lets a caller compare a whole batch
  * against a replay without exporting 65 536 records one by one. */
 int monsoon_state_hash(monsoon_t* h, uint64_t* out);

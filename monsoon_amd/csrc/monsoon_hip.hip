@@ -111,15 +111,22 @@ __device__ void wave_refill(const DevBuffers& b, int g, int which, MSB_AS_LDS ui
   __syncthreads();
 }
 
-__device__ MSB_INL RngView make_view(const DevBuffers& b, int g, uint32_t rng) {
-  MSB_RNG_PTR base = (MSB_RNG_PTR)(b.rng_out + (size_t)g * RNG_WORDS);
+// Attach game g's stream window to the record an engine works on (fields H_RNGCUR/NXT/POS).
+template <class E>
+__device__ MSB_INL void attach_rng(E& e, const DevBuffers& b, int g, uint32_t rng) {
+  const uint32_t* base = b.rng_out + (size_t)g * RNG_WORDS;
   int cur = (rng >> 16) & 1;
-  return RngView{base + cur * MT_N, base + (cur ^ 1) * MT_N, rng & 0xffffu, 0};
+  e.rng_attach(base + cur * MT_N, base + (cur ^ 1) * MT_N, rng & 0xffffu);
+}
+__device__ MSB_INL uint32_t peek_u32(const DevBuffers& b, int g, uint32_t rng) {
+  const uint32_t* base = b.rng_out + (size_t)g * RNG_WORDS;
+  int cur = (rng >> 16) & 1;
+  uint32_t pos = rng & 0xffffu;
+  return pos < (uint32_t)MT_N ? base[cur * MT_N + pos] : base[(cur ^ 1) * MT_N + pos - MT_N];
 }
 
 // Serial form for the lane-per-game API kernels: one lane owns the game.
-__device__ void lane_commit_rng(const DevBuffers& b, int g, GameMeta& m, const RngView& v) {
-  uint32_t pos = v.pos;
+__device__ void lane_commit_rng(const DevBuffers& b, int g, GameMeta& m, uint32_t pos) {
   int cur = (m.rng >> 16) & 1;
   if (pos >= (uint32_t)MT_N) {
     pos -= MT_N;
@@ -133,35 +140,33 @@ __device__ void lane_commit_rng(const DevBuffers& b, int g, GameMeta& m, const R
 }
 
 // ------------------------------------------------------------------------------------------------
-// Lane-per-game API kernels.  Block = 64 threads, state staged in LDS word-interleaved.
+// Lane-per-game API kernels.  Block = 64 threads; the records are staged in DYNAMIC LDS starting at LDS
+// address 0 (these kernels declare no static __shared__), interleaved across lanes in 16-byte granules.
 // ------------------------------------------------------------------------------------------------
 // games per 64-thread block in the API kernels: the extended record is too large for 64 LDS columns
 #if defined(MSB_EXT) && MSB_EXT
-constexpr int API_LANES = 32;
+constexpr int API_LANES = 16;
 #else
 constexpr int API_LANES = 64;
 #endif
-struct ApiLds {
-  u32x4 g[SG * API_LANES];
-};
+// LDS address 0 is avoided on purpose: an integer constant 0 cast to an LDS pointer is the null pointer,
+// which is not address 0 on this target; every region starts at LDS_ORIGIN.
+constexpr int LDS_ORIGIN = 16;
+constexpr int API_LDS_BYTES = LDS_ORIGIN + SG * API_LANES * 16;
+typedef LaneMem<API_LANES, LDS_ORIGIN> ApiMem;
+typedef Engine<ApiMem> ApiEngine;
 #define API_GAME_INDEX()                                  \
   if ((int)threadIdx.x >= API_LANES) return;              \
   int g = blockIdx.x * API_LANES + threadIdx.x;           \
   if (g >= n) return;
 
-__device__ MSB_INL LdsMem api_mem(ApiLds& lds) {
-  LdsMem m;
-  m.base = (MSB_AS_LDS uint8_t*)lds.g + threadIdx.x * 16;
-  m.stride = API_LANES * 16;
-  return m;
-}
-__device__ MSB_INL void api_load(const LdsMem& m, const uint32_t* src) {
+__device__ MSB_INL void api_load(const uint32_t* src) {
   const u32x4* s4 = (const u32x4*)src;
-  for (int c = 0; c < SG; c++) *(MSB_AS_LDS u32x4*)(m.base + c * m.stride) = s4[c];
+  for (int c = 0; c < SG; c++) *(MSB_AS_LDS u32x4*)ApiMem::b(c * 16) = s4[c];
 }
-__device__ MSB_INL void api_store(uint32_t* dst, const LdsMem& m) {
+__device__ MSB_INL void api_store(uint32_t* dst) {
   u32x4* d4 = (u32x4*)dst;
-  for (int c = 0; c < SG; c++) d4[c] = *(MSB_AS_LDS const u32x4*)(m.base + c * m.stride);
+  for (int c = 0; c < SG; c++) d4[c] = *(MSB_AS_LDS const u32x4*)ApiMem::b(c * 16);
 }
 
 __global__ void __launch_bounds__(64) k_seed(DevBuffers b, int n, const uint32_t* seeds) {
@@ -188,37 +193,32 @@ __global__ void __launch_bounds__(64) k_seed(DevBuffers b, int n, const uint32_t
 }
 
 __global__ void __launch_bounds__(64) k_init(DevBuffers b, int n, const uint8_t* decks, const uint8_t* factions) {
-  __shared__ ApiLds lds;
   API_GAME_INDEX();
-  Engine<LdsMem> e;
-  e.m = api_mem(lds);
+  ApiEngine e;
   GameMeta m = b.meta[g];
   m.rng = 0;
-  e.rng = make_view(b, g, m.rng);
+  attach_rng(e, b, g, m.rng);
   uint8_t d0[12], d1[12];
   for (int i = 0; i < 12; i++) {
     d0[i] = decks[(size_t)g * 24 + i];
     d1[i] = decks[(size_t)g * 24 + 12 + i];
   }
   e.init_game(d0, d1, factions[2 * g], factions[2 * g + 1]);
-  lane_commit_rng(b, g, m, e.rng);
+  lane_commit_rng(b, g, m, e.rng_pos());
   m.result = -2;
   m.fault = (uint8_t)e.fault();
   m.last_action = 255;
   m.steps = 0;
   m.lookahead = 0;
   b.meta[g] = m;
-  api_store(b.state + (size_t)g * SW, e.m);
+  api_store(b.state + (size_t)g * SW);
 }
 
 __global__ void __launch_bounds__(64) k_legal(DevBuffers b, int n, uint64_t* out) {
-  __shared__ ApiLds lds;
   API_GAME_INDEX();
-  Engine<LdsMem> e;
-  e.m = api_mem(lds);
-  api_load(e.m, b.state + (size_t)g * SW);
-  uint64_t mask[3];
-  e.legal_mask(mask);
+  ApiEngine e;
+  api_load(b.state + (size_t)g * SW);
+  msb_u64x4 mask = e.legal_mask_v();
   out[3 * g] = mask[0];
   out[3 * g + 1] = mask[1];
   out[3 * g + 2] = mask[2];
@@ -226,7 +226,6 @@ __global__ void __launch_bounds__(64) k_legal(DevBuffers b, int n, uint64_t* out
 
 __global__ void __launch_bounds__(64) k_step(DevBuffers b, int n, const uint8_t* actions, int8_t* reward, uint8_t* done,
                                               uint8_t* fault, uint8_t* illegal) {
-  __shared__ ApiLds lds;
   API_GAME_INDEX();
   int a = actions[g];
   reward[g] = 0;
@@ -234,47 +233,41 @@ __global__ void __launch_bounds__(64) k_step(DevBuffers b, int n, const uint8_t*
   fault[g] = 0;
   illegal[g] = 0;
   if (a == 255) return;
-  Engine<LdsMem> e;
-  e.m = api_mem(lds);
-  api_load(e.m, b.state + (size_t)g * SW);
-  uint64_t mask[3];
-  e.legal_mask(mask);
-  if (a >= 156 || !((mask[a >> 6] >> (a & 63)) & 1)) {
+  ApiEngine e;
+  api_load(b.state + (size_t)g * SW);
+  msb_u64x4 mask = e.legal_mask_v();
+  uint64_t word = a < 64 ? mask[0] : (a < 128 ? mask[1] : mask[2]);
+  if (a >= 156 || !((word >> (a & 63)) & 1)) {
     illegal[g] = 1;
     return;
   }
   GameMeta m = b.meta[g];
-  e.rng = make_view(b, g, m.rng);
-  int r = 0, d = 0;
-  e.step(a, &r, &d);
-  reward[g] = (int8_t)r;
-  done[g] = (uint8_t)d;
+  attach_rng(e, b, g, m.rng);
+  int rd = e.step(a);
+  reward[g] = (int8_t)(rd & 1);
+  done[g] = (uint8_t)((rd >> 1) & 1);
   fault[g] = (uint8_t)e.fault();
-  lane_commit_rng(b, g, m, e.rng);
+  lane_commit_rng(b, g, m, e.rng_pos());
   m.steps++;
   m.last_action = (uint8_t)a;
   if (e.fault()) m.fault = (uint8_t)e.fault();
   b.meta[g] = m;
-  api_store(b.state + (size_t)g * SW, e.m);
+  api_store(b.state + (size_t)g * SW);
 }
 
 __global__ void __launch_bounds__(64) k_observe(DevBuffers b, int n, int32_t* out, uint8_t* raises) {
-  __shared__ ApiLds lds;
   API_GAME_INDEX();
-  Engine<LdsMem> e;
-  e.m = api_mem(lds);
-  api_load(e.m, b.state + (size_t)g * SW);
+  ApiEngine e;
+  api_load(b.state + (size_t)g * SW);
   bool r = e.observation_raises();
   raises[g] = r ? 1 : 0;
   if (!r) e.observe(out + (size_t)g * MONSOON_OBS_INTS);
 }
 
 __global__ void __launch_bounds__(64) k_features(DevBuffers b, int n, double* out) {
-  __shared__ ApiLds lds;
   API_GAME_INDEX();
-  Engine<LdsMem> e;
-  e.m = api_mem(lds);
-  api_load(e.m, b.state + (size_t)g * SW);
+  ApiEngine e;
+  api_load(b.state + (size_t)g * SW);
   double f[10];
   if (e.observation_raises()) {
     for (int i = 0; i < 10; i++) f[i] = NAN;
@@ -297,31 +290,24 @@ __global__ void __launch_bounds__(64) k_status(DevBuffers b, int n, int32_t* out
 }
 
 __global__ void __launch_bounds__(64) k_export(DevBuffers b, int g, uint8_t* out, int32_t* len) {
-  __shared__ ApiLds lds;
   if (threadIdx.x != 0) return;
-  Engine<LdsMem> e;
-  e.m = api_mem(lds);
-  api_load(e.m, b.state + (size_t)g * SW);
-  RngView v = make_view(b, g, b.meta[g].rng);
-  uint32_t nx = v.next_u32();
-  *len = canon_record(e, nx, out);
+  ApiEngine e;
+  api_load(b.state + (size_t)g * SW);
+  *len = canon_record(e, peek_u32(b, g, b.meta[g].rng), out);
 }
 
 __global__ void __launch_bounds__(64) k_hash(DevBuffers b, int n, uint64_t* out) {
-  __shared__ ApiLds lds;
   API_GAME_INDEX();
-  Engine<LdsMem> e;
-  e.m = api_mem(lds);
-  api_load(e.m, b.state + (size_t)g * SW);
-  RngView v = make_view(b, g, b.meta[g].rng);
-  uint32_t nx = v.next_u32();
+  ApiEngine e;
+  api_load(b.state + (size_t)g * SW);
   uint8_t rec[CANON_MAX];
-  int len = canon_record(e, nx, rec);
+  int len = canon_record(e, peek_u32(b, g, b.meta[g].rng), rec);
   out[g] = fnv1a64(rec, len);
 }
 
 // ------------------------------------------------------------------------------------------------
 // Hot kernel: one decision (look-ahead + score + argmax + commit) per game, one wavefront per game.
+// Dynamic LDS map (bytes):  [0, SG*U*16) candidate records, lane-interleaved | parent record | best
 // ------------------------------------------------------------------------------------------------
 __device__ MSB_INL int nth_set_bit(const uint64_t mask[3], int k) {
   for (int w = 0; w < 3; w++) {
@@ -336,12 +322,20 @@ __device__ MSB_INL int nth_set_bit(const uint64_t mask[3], int k) {
   return -1;
 }
 
+template <int U>
+struct DecideLds {
+  static constexpr int PRIV = LDS_ORIGIN;
+  static constexpr int PRIV_BYTES = SG * U * 16 > MT_N * 4 ? SG * U * 16 : ((MT_N * 4 + 15) & ~15);   // doubles as the twist buffer
+  static constexpr int PAR = PRIV + PRIV_BYTES;
+  static constexpr int BEST = PAR + SG * 16;
+  static constexpr int TOTAL = BEST + SG * 16;
+};
+
 template <int U, int WPE>
 __global__ void __launch_bounds__(64, WPE) k_decide(DevBuffers b, int n, int max_turns, int write_scores) {
-  constexpr int PRIV_G = SG * U > (MT_N + 3) / 4 ? SG * U : (MT_N + 3) / 4;   // the private region doubles as the twist buffer
-  __shared__ u32x4 s_par[SG];
-  __shared__ u32x4 s_priv[PRIV_G];
-  __shared__ u32x4 s_best[SG];
+  typedef DecideLds<U> L;
+  typedef Engine<SharedMem<L::PAR>> ParEngine;
+  typedef Engine<LaneMem<U, L::PRIV>> CandEngine;
   const int g = blockIdx.x;
   const int lane = threadIdx.x;
   if (g >= n) return;
@@ -353,16 +347,16 @@ __global__ void __launch_bounds__(64, WPE) k_decide(DevBuffers b, int n, int max
     }
     return;
   }
-  MSB_AS_LDS u32x4* par = (MSB_AS_LDS u32x4*)s_par;
-  MSB_AS_LDS u32x4* priv = (MSB_AS_LDS u32x4*)s_priv;
+  MSB_AS_LDS u32x4* par = (MSB_AS_LDS u32x4*)(uintptr_t)L::PAR;
+  MSB_AS_LDS u32x4* priv = (MSB_AS_LDS u32x4*)(uintptr_t)L::PRIV;
+  MSB_AS_LDS u32x4* bestcol = (MSB_AS_LDS u32x4*)(uintptr_t)L::BEST;
   u32x4* grec = (u32x4*)(b.state + (size_t)g * SW);
   for (int c = lane; c < SG; c += 64) par[c] = grec[c];   // one coalesced 16-B-per-lane pass
   __syncthreads();
 
-  Engine<LdsMem> pe;
-  pe.m.base = (MSB_AS_LDS uint8_t*)par;
-  pe.m.stride = 16;
-  pe.rng = make_view(b, g, meta.rng);
+  ParEngine pe;
+  if (lane == 0) attach_rng(pe, b, g, meta.rng);
+  __syncthreads();
 
   // rollout contract: while not have_winner() and steps < max_turns
   if (pe.have_winner() || meta.steps >= max_turns) {
@@ -389,9 +383,7 @@ __global__ void __launch_bounds__(64, WPE) k_decide(DevBuffers b, int n, int max
   double w[10];
   for (int i = 0; i < 10; i++) w[i] = wt[i];
 
-  Engine<LdsMem> ce;
-  ce.m.base = (MSB_AS_LDS uint8_t*)(priv + lane);
-  ce.m.stride = U * 16;
+  CandEngine ce;
   // Running best over the passes (uniform across the wave).  When the legal set needs more than
   // one pass, the best successor so far is parked in a spare LDS column so that nothing is replayed.
   constexpr int NONE_A = 1 << 20;
@@ -401,7 +393,6 @@ __global__ void __launch_bounds__(64, WPE) k_decide(DevBuffers b, int n, int max
   int cfault = 0;
   int wl = 0;                       // column (lane) holding the committed successor
   const bool multi = n_legal > U;
-  MSB_AS_LDS u32x4* bestcol = (MSB_AS_LDS u32x4*)s_best;
   for (int base = 0; base < n_legal; base += U) {
     int k = base + lane;
     double s = 0.0;   // except Exception -> 0.0 (evo/heuristic_agent.py:48-51)
@@ -410,19 +401,17 @@ __global__ void __launch_bounds__(64, WPE) k_decide(DevBuffers b, int n, int max
     int my_fault = 0;
     if (lane < U && k < n_legal) {
       a = nth_set_bit(mask, k);
-      for (int c = 0; c < SG; c++) priv[c * U + lane] = par[c];   // copy.deepcopy: 16 bytes per LDS op
-      ce.rng = pe.rng;
-      int r, d;
-      ce.step(a, &r, &d);
+      for (int c = 0; c < SG; c++) priv[c * U + lane] = par[c];   // copy.deepcopy (stream window included)
+      ce.step(a);
       int f = ce.fault();
       bool raises = f == 0 && ce.observation_raises();
       if (f == 0 && !before_raises && !raises) {
         double fa[10];
         ce.features(fa);
-        s = Engine<LdsMem>::action_score(w, fb, fa);
+        s = CandEngine::action_score(w, fb, fa);
       }
       if (write_scores) b.scores[(size_t)g * MONSOON_NUM_ACTIONS + a] = s;
-      my_pos = ce.rng.pos;
+      my_pos = ce.rng_pos();
       my_fault = f ? f : (raises ? FAULT_INT_CARD : 0);
     }
     // first maximum over the ascending legal list == (max score, then min action id)
@@ -694,7 +683,7 @@ static int check_ready(monsoon_t* h) {
 
 static int launch_reset(monsoon_t* h, int n) {
   hipLaunchKernelGGL(k_seed, dim3(n), dim3(64), 0, h->stream, h->b, n, h->d_seeds);
-  hipLaunchKernelGGL(k_init, dim3((n + API_LANES - 1) / API_LANES), dim3(64), 0, h->stream, h->b, n, h->d_decks, h->d_factions);
+  hipLaunchKernelGGL(k_init, dim3((n + API_LANES - 1) / API_LANES), dim3(64), API_LDS_BYTES, h->stream, h->b, n, h->d_decks, h->d_factions);
   HIP_TRY(h, hipGetLastError());
   return MONSOON_OK;
 }
@@ -731,7 +720,7 @@ int monsoon_legal_mask(monsoon_t* h, uint64_t* out) {
   if (rc) return rc;
   if (!out) return MONSOON_ERR_ARG;
   int n = h->n;
-  hipLaunchKernelGGL(k_legal, dim3((n + API_LANES - 1) / API_LANES), dim3(64), 0, h->stream, h->b, n, h->d_masks);
+  hipLaunchKernelGGL(k_legal, dim3((n + API_LANES - 1) / API_LANES), dim3(64), API_LDS_BYTES, h->stream, h->b, n, h->d_masks);
   HIP_TRY(h, hipGetLastError());
   HIP_TRY(h, hipMemcpyAsync(out, h->d_masks, (size_t)n * 24, hipMemcpyDeviceToHost, h->stream));
   HIP_TRY(h, hipStreamSynchronize(h->stream));
@@ -745,7 +734,7 @@ int monsoon_step(monsoon_t* h, const uint8_t* actions, int8_t* reward, uint8_t* 
   int n = h->n;
   uint8_t* d = h->d_bytes;   // [actions | reward | done | fault | illegal] x n
   HIP_TRY(h, hipMemcpyAsync(d, actions, n, hipMemcpyHostToDevice, h->stream));
-  hipLaunchKernelGGL(k_step, dim3((n + API_LANES - 1) / API_LANES), dim3(64), 0, h->stream, h->b, n, d, (int8_t*)(d + n), d + 2 * (size_t)n,
+  hipLaunchKernelGGL(k_step, dim3((n + API_LANES - 1) / API_LANES), dim3(64), API_LDS_BYTES, h->stream, h->b, n, d, (int8_t*)(d + n), d + 2 * (size_t)n,
                      d + 3 * (size_t)n, d + 4 * (size_t)n);
   HIP_TRY(h, hipGetLastError());
   std::vector<uint8_t> host(4 * (size_t)n);
@@ -769,7 +758,7 @@ int monsoon_observe(monsoon_t* h, int32_t* out, uint8_t* raises) {
   if (!out) return MONSOON_ERR_ARG;
   int n = h->n;
   if (!h->d_i32) HIP_TRY(h, hipMalloc(&h->d_i32, (size_t)h->cfg.max_games * MONSOON_OBS_INTS * 4));
-  hipLaunchKernelGGL(k_observe, dim3((n + API_LANES - 1) / API_LANES), dim3(64), 0, h->stream, h->b, n, h->d_i32, h->d_bytes);
+  hipLaunchKernelGGL(k_observe, dim3((n + API_LANES - 1) / API_LANES), dim3(64), API_LDS_BYTES, h->stream, h->b, n, h->d_i32, h->d_bytes);
   HIP_TRY(h, hipGetLastError());
   HIP_TRY(h, hipMemcpyAsync(out, h->d_i32, (size_t)n * MONSOON_OBS_INTS * 4, hipMemcpyDeviceToHost, h->stream));
   std::vector<uint8_t> r(n);
@@ -785,7 +774,7 @@ int monsoon_features(monsoon_t* h, double* out) {
   if (!out) return MONSOON_ERR_ARG;
   int n = h->n;
   if (!h->d_f64) HIP_TRY(h, hipMalloc(&h->d_f64, (size_t)h->cfg.max_games * 10 * 8));
-  hipLaunchKernelGGL(k_features, dim3((n + API_LANES - 1) / API_LANES), dim3(64), 0, h->stream, h->b, n, h->d_f64);
+  hipLaunchKernelGGL(k_features, dim3((n + API_LANES - 1) / API_LANES), dim3(64), API_LDS_BYTES, h->stream, h->b, n, h->d_f64);
   HIP_TRY(h, hipGetLastError());
   HIP_TRY(h, hipMemcpyAsync(out, h->d_f64, (size_t)n * 80, hipMemcpyDeviceToHost, h->stream));
   HIP_TRY(h, hipStreamSynchronize(h->stream));
@@ -809,7 +798,7 @@ int monsoon_state_export(monsoon_t* h, int32_t idx, uint8_t* buf, int32_t* len) 
   int rc = check_ready(h);
   if (rc) return rc;
   if (!buf || !len || idx < 0 || idx >= h->n) return MONSOON_ERR_ARG;
-  hipLaunchKernelGGL(k_export, dim3(1), dim3(64), 0, h->stream, h->b, idx, h->d_bytes, (int32_t*)(h->d_bytes + 2048));
+  hipLaunchKernelGGL(k_export, dim3(1), dim3(64), API_LDS_BYTES, h->stream, h->b, idx, h->d_bytes, (int32_t*)(h->d_bytes + 2048));
   HIP_TRY(h, hipGetLastError());
   uint8_t host[2048 + 4];
   HIP_TRY(h, hipMemcpyAsync(host, h->d_bytes, sizeof(host), hipMemcpyDeviceToHost, h->stream));
@@ -821,12 +810,23 @@ int monsoon_state_export(monsoon_t* h, int32_t idx, uint8_t* buf, int32_t* len) 
   return MONSOON_OK;
 }
 
+// Raw record bytes of game idx as they sit in HBM (debugging aid; layout = state.h, not part of the parity surface).
+int monsoon_debug_raw(monsoon_t* h, int32_t idx, uint8_t* buf, int32_t* len) {
+  int rc = check_ready(h);
+  if (rc) return rc;
+  if (!buf || !len || idx < 0 || idx >= h->n) return MONSOON_ERR_ARG;
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  HIP_TRY(h, hipMemcpy(buf, h->b.state + (size_t)idx * SW, STATE_BYTES, hipMemcpyDeviceToHost));
+  *len = STATE_BYTES;
+  return MONSOON_OK;
+}
+
 int monsoon_state_hash(monsoon_t* h, uint64_t* out) {
   int rc = check_ready(h);
   if (rc) return rc;
   if (!out) return MONSOON_ERR_ARG;
   int n = h->n;
-  hipLaunchKernelGGL(k_hash, dim3((n + API_LANES - 1) / API_LANES), dim3(64), 0, h->stream, h->b, n, h->d_masks);
+  hipLaunchKernelGGL(k_hash, dim3((n + API_LANES - 1) / API_LANES), dim3(64), API_LDS_BYTES, h->stream, h->b, n, h->d_masks);
   HIP_TRY(h, hipGetLastError());
   HIP_TRY(h, hipMemcpyAsync(out, h->d_masks, (size_t)n * 8, hipMemcpyDeviceToHost, h->stream));
   HIP_TRY(h, hipStreamSynchronize(h->stream));
@@ -872,7 +872,7 @@ static int launch_decide(monsoon_t* h, int n, int max_turns, int write_scores, b
     HIP_TRY(h, hipEventCreate(&e1));
     HIP_TRY(h, hipEventRecord(e0, h->stream));
   }
-#define MSB_LAUNCH(U, W) hipLaunchKernelGGL((k_decide<U, W>), dim3(n), dim3(64), 0, h->stream, h->b, n, max_turns, write_scores)
+#define MSB_LAUNCH(U, W) hipLaunchKernelGGL((k_decide<U, W>), dim3(n), dim3(64), DecideLds<U>::TOTAL, h->stream, h->b, n, max_turns, write_scores)
   int variant = h->cfg.lanes_per_game * 10 + h->wpe;
   switch (variant) {
     case 81: MSB_LAUNCH(8, 1); break;

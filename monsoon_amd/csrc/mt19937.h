@@ -48,55 +48,15 @@ MSB_HD inline void mt_twist(uint32_t* mt) {
   mt[MT_N - 1] = mt[MT_M - 1] ^ mt_mix(mt[MT_N - 1], mt[0]);
 }
 
-// A read-only window over two consecutive blocks of TEMPERED outputs of one game's stream:
-// `cur` is the block the game's cursor is in, `nxt` the one after it.  A look-ahead step keeps a
-// private cursor (the reference's copy.deepcopy clones the stream, evo/game_adapter.py:284), so
-// many candidate steps of one decision read the same window.  Consuming more than the window
-// sets `overrun` (FAULT_RNG_OVERRUN): a single step would have to draw > 624 words.
+// The stream a game step sees is a read-only window over two consecutive blocks of TEMPERED outputs
+// (current + next) with a cursor; the window and the cursor are fields of the state record (state.h:
+// H_RNGCUR, H_RNGNXT, H_RNGPOS) and the draw functions are Engine methods (rules.h: rng_*).  A look-ahead
+// step keeps a private cursor (the reference's copy.deepcopy clones the stream,
+// evo/game_adapter.py:284), so many candidate steps of one decision read the same window.
 #if defined(__HIPCC__)
 #define MSB_RNG_PTR __attribute__((address_space(1))) const uint32_t*   // global_load, not flat_load
 #else
 #define MSB_RNG_PTR const uint32_t*
 #endif
-struct RngView {
-  MSB_RNG_PTR cur;
-  MSB_RNG_PTR nxt;
-  uint32_t pos;      // index of the next word, 0..1247 (>= 624 reads nxt)
-  uint32_t overrun;
-
-  MSB_HD MSB_INL uint32_t next_u32() {
-    uint32_t i = pos;
-    if (i < (uint32_t)MT_N) {
-      pos = i + 1;
-      return cur[i];
-    }
-    if (i < (uint32_t)(2 * MT_N)) {
-      pos = i + 1;
-      return nxt[i - MT_N];
-    }
-    overrun = 1;
-    return 0;
-  }
-  // rk_interval / buffered_bounded_masked_uint32 for max <= 0xffffffff
-  MSB_HD MSB_INL uint32_t interval(uint32_t max) {
-    if (max == 0) return 0;
-    uint32_t mask = max;
-    mask |= mask >> 1;
-    mask |= mask >> 2;
-    mask |= mask >> 4;
-    mask |= mask >> 8;
-    mask |= mask >> 16;
-    uint32_t v;
-    do {
-      v = next_u32() & mask;
-    } while (v > max && !overrun);
-    return v;
-  }
-  MSB_HD MSB_INL int randint(int lo, int hi) { return lo + (int)interval((uint32_t)(hi - 1 - lo)); }
-  MSB_HD MSB_INL double random_sample() {
-    uint32_t a = next_u32() >> 5, b = next_u32() >> 6;
-    return ((double)a * 67108864.0 + (double)b) / 9007199254740992.0;
-  }
-};
 
 }  // namespace msb

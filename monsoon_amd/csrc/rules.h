@@ -122,7 +122,49 @@ constexpr int MAX_DEPTH = 40;
 template <class M>
 struct Engine {
   M m;
-  RngView rng;
+
+  // ---- numpy legacy RandomState draws over the record's stream window (mt19937.h) ----------------
+  MSB_HD MSB_INL uint32_t rng_next_u32() {
+    uint32_t i = (uint32_t)m.ld16(H_RNGPOS) & 0xffffu;
+    if (i < (uint32_t)(2 * MT_N)) {
+      uint64_t blk = m.ld64(i < (uint32_t)MT_N ? H_RNGCUR : H_RNGNXT);
+      if (blk == 0) {   // no stream window attached to this record: flag it, never dereference
+        m.st8(H_RNGOVER, 1);
+        return 0;
+      }
+      m.st16(H_RNGPOS, (int)(i + 1));
+      return ((MSB_RNG_PTR)(uintptr_t)blk)[i < (uint32_t)MT_N ? i : i - MT_N];
+    }
+    m.st8(H_RNGOVER, 1);   // a single step would have to draw more than 624 words
+    return 0;
+  }
+  // rk_interval / buffered_bounded_masked_uint32 for max <= 0xffffffff
+  MSB_HD MSB_INL uint32_t rng_interval(uint32_t max) {
+    if (max == 0) return 0;
+    uint32_t mask = max;
+    mask |= mask >> 1;
+    mask |= mask >> 2;
+    mask |= mask >> 4;
+    mask |= mask >> 8;
+    mask |= mask >> 16;
+    uint32_t v;
+    do {
+      v = rng_next_u32() & mask;
+    } while (v > max && !m.ld8(H_RNGOVER));
+    return v;
+  }
+  MSB_HD MSB_INL int rng_randint(int lo, int hi) { return lo + (int)rng_interval((uint32_t)(hi - 1 - lo)); }
+  MSB_HD MSB_INL double rng_random_sample() {
+    uint32_t a = rng_next_u32() >> 5, b = rng_next_u32() >> 6;
+    return ((double)a * 67108864.0 + (double)b) / 9007199254740992.0;
+  }
+  MSB_HD MSB_INL void rng_attach(const uint32_t* cur, const uint32_t* nxt, uint32_t pos) {
+    m.st64(H_RNGCUR, (uint64_t)(uintptr_t)cur);
+    m.st64(H_RNGNXT, (uint64_t)(uintptr_t)nxt);
+    m.st16(H_RNGPOS, (int)pos);
+    m.st8(H_RNGOVER, 0);
+  }
+  MSB_HD MSB_INL uint32_t rng_pos() const { return (uint32_t)m.ld16(H_RNGPOS) & 0xffffu; }
 
   // ------------------------------------------------------------------------------------------
   // raw field access
@@ -686,11 +728,11 @@ struct Engine {
   }
 
   // numpy RandomState.choice(list) / shuffle(list)
-  MSB_HD MSB_INL int choice_index(int n) { return rng.randint(0, n); }
+  MSB_HD MSB_INL int choice_index(int n) { return rng_randint(0, n); }
   MSB_HD MSB_INL P choice_point(PList l) { return l.at(choice_index(l.n())); }
   MSB_HD MSB_NOINLINE PList shuffle(PList l) {
     for (int i = l.n() - 1; i >= 1; i--) {
-      int j = (int)rng.interval((uint32_t)i);
+      int j = (int)rng_interval((uint32_t)i);
       int tmp = l.get(i);
       l.set(i, l.get(j));
       l.set(j, tmp);
@@ -708,7 +750,7 @@ struct Engine {
     for (int i = 0; i < m; i++) {
       P p = l.at(i);
       int kv = key_mode == 0 ? p.y : e_str(at(p));
-      double rv = rng.random_sample();
+      double rv = rng_random_sample();
       // does element i sort strictly before the current best / second best?
       bool lt0 = b0 < 0 || (rev ? (kv > k0 || (kv == k0 && rv > r0)) : (kv < k0 || (kv == k0 && rv < r0)));
       if (lt0) {
@@ -896,7 +938,7 @@ struct Engine {
         else if (position.x == 3)
           dx = -1;                                 // choice([-1]): no draw
         else
-          dx = rng.randint(0, 2) ? 1 : -1;         // choice([-1, 1])
+          dx = rng_randint(0, 2) ? 1 : -1;         // choice([-1, 1])
         dest = P{position.x + dx, position.y};
         confused_cached--;
       } else if (on_play && !e_ff(e) && dest.y != (is_local ? -1 : 5) &&
@@ -1189,7 +1231,7 @@ struct Engine {
         double p = deck_w(o, i) / sum;
         last = (i == 0) ? p : last + p;   // ndarray.cumsum: sequential
       }
-      double u = rng.random_sample();
+      double u = rng_random_sample();
       int idx = 0;
       double acc = 0.0;
       for (; idx < n; idx++) {
@@ -1401,9 +1443,11 @@ struct Engine {
     mask[2] = r[2];
   }
 
-  // Stormbound.step, games/stormbound.py:318-373 (without the observation; see features.h).
-  // The caller guarantees `action` is in legal_actions().  reward/done as the reference returns.
-  MSB_HD MSB_NOINLINE void step(int action, int* reward, int* done) {
+  // Stormbound.step, games/stormbound.py:318-373 (without the observation; see observe.inc).
+  // The caller guarantees `action` is in legal_actions().  Returns reward | done << 1 as the reference
+  // computes them (in registers: no out-pointers behind a non-inlined call).
+  MSB_HD MSB_NOINLINE int step(int action) {
+    int result = 0;
     begin_step();
     int lo = local();
     if (action < 64) {
@@ -1437,22 +1481,27 @@ struct Engine {
 #endif
       m.st8(pl(lo, P_FLAGS), m.ld8(pl(lo, P_FLAGS)) & ~2);
     }
-    if (fault()) return;
+    if (fault()) return 0;
     // done = have_winner() or len(legal_actions()) == 0; legal_actions() is never empty (PASS)
-    if (done) *done = have_winner() ? 1 : 0;
-    if (reward) *reward = pl_base(remote()) <= 0 ? 1 : 0;
+    result = (pl_base(remote()) <= 0 ? 1 : 0) | (have_winner() ? 2 : 0);
     if (action == 155) {
       m.st8(H_TOPLAY, lo ^ 1);
       flip();
       to_next_turn();
     }
-    if (rng.overrun) set_fault(FAULT_RNG_OVERRUN);
+    if (m.ld8(H_RNGOVER)) set_fault(FAULT_RNG_OVERRUN);
+    return result;
   }
 
   // Game construction: Stormbound.__init__ / Player.__init__ (games/stormbound.py:293-304,
   // player.py:13-37).  deck0/deck1: 12 card indices in constructor order.
   MSB_HD MSB_NOINLINE void init_game(const uint8_t* deck0, const uint8_t* deck1, int faction0, int faction1) {
+    uint64_t rc = m.ld64(H_RNGCUR), rn = m.ld64(H_RNGNXT);
+    uint32_t rp = rng_pos();
     for (int w = 0; w < STATE_WORDS; w++) m.st32(4 * w, 0);
+    m.st64(H_RNGCUR, rc);
+    m.st64(H_RNGNXT, rn);
+    m.st16(H_RNGPOS, (int)rp);
     for (int t = 0; t < 20; t++) board_put(t, SLOT_NONE);
     for (int e = 0; e < NUM_ENT; e++) m.st8(E_CARD + e, CARD_NONE);
     if (REM_LISTS)
@@ -1476,7 +1525,7 @@ struct Engine {
         if (g_cards[d[i]].int_id < 0) m.st8(H_OBSFAULT, 1);
       }
       for (int i = DECK_SIZE - 1; i >= 1; i--) {  // random.shuffle(self.deck)
-        int j = (int)rng.interval((uint32_t)i);
+        int j = (int)rng_interval((uint32_t)i);
         uint8_t tmp = d[i];
         d[i] = d[j];
         d[j] = tmp;
@@ -1498,7 +1547,7 @@ struct Engine {
       m.st8(pl(o, P_DECK_N), DECK_SIZE);
       fill_hand(o);
     }
-    if (rng.overrun) set_fault(FAULT_RNG_OVERRUN);
+    if (m.ld8(H_RNGOVER)) set_fault(FAULT_RNG_OVERRUN);
   }
 
   // ------------------------------------------------------------------------------------------

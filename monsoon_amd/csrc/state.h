@@ -51,11 +51,16 @@ constexpr int H_DEPTH = 6;      // recursion guard (build limit)
 constexpr int H_CP = 7;         // order of board.current_player
 constexpr int H_HIST = 8;       // 4 x {owner, card}; oldest first
 constexpr int H_USED = 16;      // u32: entity slots referenced since the start of this step
-constexpr int H_STEPS = 20;     // u16 (reserved)
+// The game's numpy stream as this record sees it (transient: set when the record is staged for a step, the
+// cursor is written back by the caller): two resident blocks of tempered MT19937 outputs and a cursor.
+constexpr int H_RNGPOS = 20;    // u16 index of the next word, 0..1247 (>= 624 reads the second block)
 constexpr int H_OBSFAULT = 22;  // 1 if a deck holds up01/up02/up03: only then can get_observation raise (card.py:46)
+constexpr int H_RNGOVER = 23;   // set when a step wanted more than the two resident blocks
 constexpr int OFF_BOARD = 24;   // 20 x u8 slot
 constexpr int OFF_TRIG = 44;    // TRIG_CAP x u8 (slot | has_source<<7)
-constexpr int OFF_PL = 64;
+constexpr int H_RNGCUR = 64;    // u64 address of the current block of tempered outputs
+constexpr int H_RNGNXT = 72;    // u64 address of the next block
+constexpr int OFF_PL = 80;
 
 // ---- player -------------------------------------------------------------------------------------
 constexpr int P_BASE = 0;       // i16 Player.strength
@@ -121,32 +126,8 @@ struct FlatMem {
   MSB_HD MSB_INL void st32(int o, uint32_t v) { *(uint32_t*)(p + o) = v; }
   MSB_HD MSB_INL double ldf(int o) const { return *(const double*)(p + o); }
   MSB_HD MSB_INL void stf(int o, double v) { *(double*)(p + o) = v; }
-};
-
-// Word-interleaved: word w of this record is at base[w * stride]; `base` already points at this
-// record's column (lane or game).  Used for LDS (stride = lanes per wave) and HBM (stride = batch).
-struct StridedMem {
-  uint32_t* base;
-  int stride;
-  MSB_HD MSB_INL uint8_t* b(int o) const { return (uint8_t*)(base + (o >> 2) * stride) + (o & 3); }
-  MSB_HD MSB_INL int ld8(int o) const { return *b(o); }
-  MSB_HD MSB_INL void st8(int o, int v) { *b(o) = (uint8_t)v; }
-  MSB_HD MSB_INL int ld16(int o) const { return *(const int16_t*)b(o); }
-  MSB_HD MSB_INL void st16(int o, int v) { *(int16_t*)b(o) = (int16_t)v; }
-  MSB_HD MSB_INL uint32_t ld32(int o) const { return base[(o >> 2) * stride]; }
-  MSB_HD MSB_INL void st32(int o, uint32_t v) { base[(o >> 2) * stride] = v; }
-  MSB_HD MSB_INL double ldf(int o) const {
-    union { uint32_t u[2]; double d; } x;
-    x.u[0] = ld32(o);
-    x.u[1] = ld32(o + 4);
-    return x.d;
-  }
-  MSB_HD MSB_INL void stf(int o, double v) {
-    union { uint32_t u[2]; double d; } x;
-    x.d = v;
-    st32(o, x.u[0]);
-    st32(o + 4, x.u[1]);
-  }
+  MSB_HD MSB_INL uint64_t ld64(int o) const { return *(const uint64_t*)(p + o); }
+  MSB_HD MSB_INL void st64(int o, uint64_t v) { *(uint64_t*)(p + o) = v; }
 };
 
 #if defined(__HIPCC__)
@@ -158,18 +139,40 @@ struct StridedMem {
 // lane l sits at (c*LANES + l)*16.  A lane's record is copied 16 bytes at a time (ds_read_b128 /
 // ds_write_b128, conflict-free: consecutive lanes touch consecutive 16-byte slots), f64 weights are one
 // ds_read_b64, and with 8 lanes per game a same-field access by all lanes still hits 8 distinct banks.
-struct LdsMem {
-  MSB_AS_LDS uint8_t* base;    // this lane's granule 0
-  int stride;                  // bytes between consecutive granules of one lane (= lanes * 16)
-  MSB_HD MSB_INL MSB_AS_LDS uint8_t* b(int o) const { return base + (o >> 4) * stride + (o & 15); }
-  MSB_HD MSB_INL int ld8(int o) const { return *b(o); }
-  MSB_HD MSB_INL void st8(int o, int v) { *b(o) = (uint8_t)v; }
-  MSB_HD MSB_INL int ld16(int o) const { return *(MSB_AS_LDS const int16_t*)b(o); }
-  MSB_HD MSB_INL void st16(int o, int v) { *(MSB_AS_LDS int16_t*)b(o) = (int16_t)v; }
-  MSB_HD MSB_INL uint32_t ld32(int o) const { return *(MSB_AS_LDS const uint32_t*)b(o); }
-  MSB_HD MSB_INL void st32(int o, uint32_t v) { *(MSB_AS_LDS uint32_t*)b(o) = v; }
-  MSB_HD MSB_INL double ldf(int o) const { return *(MSB_AS_LDS const double*)b(o); }
-  MSB_HD MSB_INL void stf(int o, double v) { *(MSB_AS_LDS double*)b(o) = v; }
+//
+// The accessors are STATELESS: the kernels use only dynamic LDS, so the image starts at LDS address
+// BASE (a compile-time constant) and the lane is the work-item id.  An Engine over such an accessor is an
+// empty object -- nothing has to be reloaded through `this` behind the non-inlined (recursive) calls of
+// the rules core, which cost a flat_load round trip per call when the accessor held a pointer.
+template <int LANES, int BASE>
+struct LaneMem {   // this lane's private record among LANES interleaved ones
+  MSB_HD MSB_INL static MSB_AS_LDS uint8_t* b(int o) {
+    return (MSB_AS_LDS uint8_t*)(uintptr_t)(BASE + (o >> 4) * (LANES * 16) + (o & 15) + (int)__builtin_amdgcn_workitem_id_x() * 16);
+  }
+  MSB_HD MSB_INL static int ld8(int o) { return *b(o); }
+  MSB_HD MSB_INL static void st8(int o, int v) { *b(o) = (uint8_t)v; }
+  MSB_HD MSB_INL static int ld16(int o) { return *(MSB_AS_LDS const int16_t*)b(o); }
+  MSB_HD MSB_INL static void st16(int o, int v) { *(MSB_AS_LDS int16_t*)b(o) = (int16_t)v; }
+  MSB_HD MSB_INL static uint32_t ld32(int o) { return *(MSB_AS_LDS const uint32_t*)b(o); }
+  MSB_HD MSB_INL static void st32(int o, uint32_t v) { *(MSB_AS_LDS uint32_t*)b(o) = v; }
+  MSB_HD MSB_INL static double ldf(int o) { return *(MSB_AS_LDS const double*)b(o); }
+  MSB_HD MSB_INL static void stf(int o, double v) { *(MSB_AS_LDS double*)b(o) = v; }
+  MSB_HD MSB_INL static uint64_t ld64(int o) { return *(MSB_AS_LDS const uint64_t*)b(o); }
+  MSB_HD MSB_INL static void st64(int o, uint64_t v) { *(MSB_AS_LDS uint64_t*)b(o) = v; }
+};
+template <int BASE>
+struct SharedMem {   // one contiguous record read by every lane of the wave (LDS broadcast)
+  MSB_HD MSB_INL static MSB_AS_LDS uint8_t* b(int o) { return (MSB_AS_LDS uint8_t*)(uintptr_t)(BASE + o); }
+  MSB_HD MSB_INL static int ld8(int o) { return *b(o); }
+  MSB_HD MSB_INL static void st8(int o, int v) { *b(o) = (uint8_t)v; }
+  MSB_HD MSB_INL static int ld16(int o) { return *(MSB_AS_LDS const int16_t*)b(o); }
+  MSB_HD MSB_INL static void st16(int o, int v) { *(MSB_AS_LDS int16_t*)b(o) = (int16_t)v; }
+  MSB_HD MSB_INL static uint32_t ld32(int o) { return *(MSB_AS_LDS const uint32_t*)b(o); }
+  MSB_HD MSB_INL static void st32(int o, uint32_t v) { *(MSB_AS_LDS uint32_t*)b(o) = v; }
+  MSB_HD MSB_INL static double ldf(int o) { return *(MSB_AS_LDS const double*)b(o); }
+  MSB_HD MSB_INL static void stf(int o, double v) { *(MSB_AS_LDS double*)b(o) = v; }
+  MSB_HD MSB_INL static uint64_t ld64(int o) { return *(MSB_AS_LDS const uint64_t*)b(o); }
+  MSB_HD MSB_INL static void st64(int o, uint64_t v) { *(MSB_AS_LDS uint64_t*)b(o) = v; }
 };
 #endif
 

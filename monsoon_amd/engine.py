@@ -97,6 +97,12 @@ class BatchEngine:
         self._ck(self.lib.monsoon_state_export(self.h, i, _ptr(buf), ctypes.byref(ln)), "monsoon_state_export")
         return buf[:ln.value].tobytes()
 
+    def debug_raw(self, i):
+        buf = np.zeros(4096, dtype=np.uint8)
+        ln = ctypes.c_int32()
+        self._ck(self.lib.monsoon_debug_raw(self.h, i, _ptr(buf), ctypes.byref(ln)), "monsoon_debug_raw")
+        return buf[:ln.value].copy()
+
     def state_hash(self):
         out = np.zeros(self.n, dtype=np.uint64)
         self._ck(self.lib.monsoon_state_hash(self.h, _ptr(out)), "monsoon_state_hash")

@@ -53,11 +53,9 @@ void seed_game(Game& g, uint32_t seed) {
   refill(g, 1);
 }
 
-RngView view(const Game& g) { return RngView{g.out[g.cur], g.out[g.cur ^ 1], g.pos, 0}; }
-
-// advance the game's stream to a view's cursor
-void commit_rng(Game& g, const RngView& v) {
-  g.pos = v.pos;
+// advance the game's stream to the cursor a step left in the record
+void commit_rng(Game& g, Engine<FlatMem>& e) {
+  g.pos = e.rng_pos();
   if (g.pos >= (uint32_t)MT_N) {
     g.pos -= MT_N;
     int old = g.cur;
@@ -66,17 +64,15 @@ void commit_rng(Game& g, const RngView& v) {
   }
 }
 
+// an engine over the game's record with the stream window attached at the game's cursor
 Engine<FlatMem> engine(Game& g) {
   Engine<FlatMem> e;
   e.m.p = g.st;
-  e.rng = view(g);
+  e.rng_attach(g.out[g.cur], g.out[g.cur ^ 1], g.pos);
   return e;
 }
 
-uint32_t peek(const Game& g) {
-  RngView v = view(g);
-  return v.next_u32();
-}
+uint32_t peek(const Game& g) { return g.pos < (uint32_t)MT_N ? g.out[g.cur][g.pos] : g.out[g.cur ^ 1][g.pos - MT_N]; }
 
 int game_result(Engine<FlatMem>& e) {
   // SURVEY §8c rollout contract (mirrors evo/fitness.py:160-166 scoring)
@@ -107,8 +103,7 @@ int decide(Game& g, const double* w, double* scores_out, int* n_legal_out, uint6
     n_legal++;
     Game c = g;  // copy.deepcopy(self.game), evo/game_adapter.py:284 (stream included)
     Engine<FlatMem> ce = engine(c);
-    int r, d;
-    ce.step(a, &r, &d);
+    ce.step(a);
     g.lookahead_steps++;
     double s = 0.0;  // except Exception -> 0.0 (evo/heuristic_agent.py:48-51)
     if (!ce.fault() && !before_raises && !ce.observation_raises()) {
@@ -129,11 +124,10 @@ int decide(Game& g, const double* w, double* scores_out, int* n_legal_out, uint6
 // adapter = adapter.apply_action(action): commit.  Returns the fault code of the step.
 int commit(Game& g, int action) {
   Engine<FlatMem> e = engine(g);
-  int r, d;
-  e.step(action, &r, &d);
+  e.step(action);
   int f = e.fault();
   if (!f && e.observation_raises()) f = FAULT_INT_CARD;  // step() returns get_observation()
-  commit_rng(g, e.rng);
+  commit_rng(g, e);
   g.steps++;
   return f;
 }
@@ -162,7 +156,7 @@ int orc_reset(void* h, int gi, uint32_t seed, const uint8_t* deck0, const uint8_
   g.lookahead_steps = 0;
   Engine<FlatMem> e = engine(g);
   e.init_game(deck0, deck1, f0, f1);
-  commit_rng(g, e.rng);
+  commit_rng(g, e);
   return e.fault();
 }
 
@@ -176,9 +170,11 @@ void orc_legal(void* h, int gi, uint64_t* mask3) {
 int orc_step(void* h, int gi, int action, int* reward, int* done) {
   Game& g = ((Oracle*)h)->games[gi];
   Engine<FlatMem> e = engine(g);
-  e.step(action, reward, done);
+  int rd = e.step(action);
+  if (reward) *reward = rd & 1;
+  if (done) *done = (rd >> 1) & 1;
   int f = e.fault();
-  commit_rng(g, e.rng);
+  commit_rng(g, e);
   g.steps++;
   return f;
 }
@@ -216,6 +212,8 @@ uint64_t orc_obs_hash(void* h, int gi) {
   if (orc_observe(h, gi, obs)) return 0;
   return fnv1a64((const uint8_t*)obs, sizeof(obs));
 }
+
+void orc_raw(void* h, int gi, uint8_t* buf) { memcpy(buf, ((Oracle*)h)->games[gi].st, STATE_BYTES); }
 
 int orc_have_winner(void* h, int gi) {
   Game& g = ((Oracle*)h)->games[gi];
@@ -286,47 +284,51 @@ uint64_t orc_rollout_batch(void* h, int n, const double* w, int max_turns, int n
 // ---- RNG known-answer entry points (tests/golden/rng_kat.npz) ---------------------------------
 void orc_rng_u32(uint32_t seed, int n, uint32_t* out) {
   Game g;
+  memset(&g, 0, sizeof(g));
   seed_game(g, seed);
   for (int i = 0; i < n; i++) {
-    RngView v = view(g);
-    out[i] = v.next_u32();
-    commit_rng(g, v);
+    Engine<FlatMem> e = engine(g);
+    out[i] = e.rng_next_u32();
+    commit_rng(g, e);
   }
 }
 void orc_rng_random(uint32_t seed, int n, double* out) {
   Game g;
+  memset(&g, 0, sizeof(g));
   seed_game(g, seed);
   for (int i = 0; i < n; i++) {
-    RngView v = view(g);
-    out[i] = v.random_sample();
-    commit_rng(g, v);
+    Engine<FlatMem> e = engine(g);
+    out[i] = e.rng_random_sample();
+    commit_rng(g, e);
   }
 }
 // out[i] = randint(0, bounds[i])
 void orc_rng_randint(uint32_t seed, int n, const int* bounds, int* out) {
   Game g;
+  memset(&g, 0, sizeof(g));
   seed_game(g, seed);
   for (int i = 0; i < n; i++) {
-    RngView v = view(g);
-    out[i] = v.randint(0, bounds[i]);
-    commit_rng(g, v);
+    Engine<FlatMem> e = engine(g);
+    out[i] = e.rng_randint(0, bounds[i]);
+    commit_rng(g, e);
   }
 }
 // shuffle(list(range(k))) repeated `reps` times on one stream
 void orc_rng_shuffle(uint32_t seed, int k, int reps, int* out) {
   Game g;
+  memset(&g, 0, sizeof(g));
   seed_game(g, seed);
   for (int r = 0; r < reps; r++) {
-    RngView v = view(g);
+    Engine<FlatMem> e = engine(g);
     int* a = out + r * k;
     for (int i = 0; i < k; i++) a[i] = i;
     for (int i = k - 1; i >= 1; i--) {
-      int j = (int)v.interval((uint32_t)i);
+      int j = (int)e.rng_interval((uint32_t)i);
       int t = a[i];
       a[i] = a[j];
       a[j] = t;
     }
-    commit_rng(g, v);
+    commit_rng(g, e);
   }
 }
 int orc_pyset_list(const uint8_t* keys, int n, uint8_t* out) { return pyset_list(keys, n, out); }
