@@ -328,7 +328,8 @@ struct DecideLds {
   static constexpr int PRIV_BYTES = SG * U * 16 > MT_N * 4 ? SG * U * 16 : ((MT_N * 4 + 15) & ~15);   // doubles as the twist buffer
   static constexpr int PAR = PRIV + PRIV_BYTES;
   static constexpr int BEST = PAR + SG * 16;
-  static constexpr int TOTAL = BEST + SG * 16;
+  static constexpr int WF = BEST + SG * 16;          // 10 weights + 10 "before" features (f64), shared by the lanes
+  static constexpr int TOTAL = WF + 160;
 };
 
 template <int U, int WPE>
@@ -377,11 +378,17 @@ __global__ void __launch_bounds__(64, WPE) k_decide(DevBuffers b, int n, int max
   const uint64_t mask[3] = {lm[0], lm[1], lm[2]};
   const int n_legal = __popcll(mask[0]) + __popcll(mask[1]) + __popcll(mask[2]);
   const bool before_raises = pe.observation_raises();
-  double fb[10];
-  if (!before_raises) pe.features(fb);
-  const double* wt = b.weights + (size_t)(pe.local() == 0 ? meta.p1 : meta.p2) * 10;
-  double w[10];
-  for (int i = 0; i < 10; i++) w[i] = wt[i];
+  // weights and "before" features are parked in LDS: 40 fewer live VGPRs across the recursive step calls
+  MSB_AS_LDS double* wf = (MSB_AS_LDS double*)(uintptr_t)L::WF;
+  {
+    double fb[10];
+    if (!before_raises) pe.features(fb);
+    const double* wt = b.weights + (size_t)(pe.local() == 0 ? meta.p1 : meta.p2) * 10;
+    if (lane < 10) wf[lane] = wt[lane];
+    if (lane == 0 && !before_raises)
+      for (int i = 0; i < 10; i++) wf[10 + i] = fb[i];
+  }
+  __syncthreads();
 
   CandEngine ce;
   // Running best over the passes (uniform across the wave).  When the legal set needs more than
@@ -406,9 +413,13 @@ __global__ void __launch_bounds__(64, WPE) k_decide(DevBuffers b, int n, int max
       int f = ce.fault();
       bool raises = f == 0 && ce.observation_raises();
       if (f == 0 && !before_raises && !raises) {
-        double fa[10];
+        double fa[10], wv[10], fbv[10];
         ce.features(fa);
-        s = CandEngine::action_score(w, fb, fa);
+        for (int i = 0; i < 10; i++) {
+          wv[i] = wf[i];
+          fbv[i] = wf[10 + i];
+        }
+        s = CandEngine::action_score(wv, fbv, fa);
       }
       if (write_scores) b.scores[(size_t)g * MONSOON_NUM_ACTIONS + a] = s;
       my_pos = ce.rng_pos();
