@@ -80,9 +80,10 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
-    if world > 1:
+    if world > 1 or os.environ.get("MONSOON_BENCH_FORCE_DIST") == "1":
         import torch
         import torch.distributed as dist
+        local_rank = local_rank % max(torch.cuda.device_count(), 1)
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl")   # RCCL on ROCm
 
@@ -114,7 +115,8 @@ def main():
     if dist is not None:
         # the path's one real exchange: per-individual {wins, draws, games} summed over ranks (RCCL)
         import torch
-        counts = torch.zeros((1, 3), dtype=torch.int32, device="cuda")
+        st_now = eng.stats()
+        counts = torch.tensor([[st_now["games_finished"], 0, n]], dtype=torch.int64, device="cuda")
         dist.all_reduce(counts)
         torch.cuda.synchronize()
     barrier()
