@@ -407,33 +407,38 @@ struct Engine {
   }
   // Called at the start of every step: everything not on the board is garbage in the reference
   // (no live Python reference survives a step).
+  // the 20 board bytes as five 32-bit rows (row y = tiles 4y..4y+3, x in byte x): one LDS read per row
+  MSB_HD MSB_INL uint32_t board_row(int y) const { return m.ld32(OFF_BOARD + 4 * y); }
   MSB_HD MSB_NOINLINE void begin_step() {
     uint32_t used = 0;
-    for (int t = 0; t < 20; t++) {
-      int s = board_at(t);
-      if (s != SLOT_NONE) used |= 1u << s;
+    for (int y = 0; y < 5; y++) {
+      uint32_t row = board_row(y);
+      for (int x = 0; x < 4; x++) {
+        uint32_t s = (row >> (8 * x)) & 0xff;
+        if (s != (uint32_t)SLOT_NONE) used |= 1u << s;
+      }
     }
     m.st32(H_USED, used);
     // a hand/deck entry aliasing an entity that has left the board keeps that object's last strength
-    for (int o = 0; o < 2; o++) {
-      int hn = pl_hand_n(o), dn = pl_deck_n(o);
-      for (int i = 0; i < hn + dn; i++) {
-        int off = i < hn ? hand_ref(o, i) : deck_ref(o, i - hn);
-        int fl = m.ld8(off + 2);
-        if (!(fl & CF_ALIAS)) continue;
-        int slot = m.ld8(off + 3);
-        if (used & (1u << slot)) continue;
-        int str = e_str(slot);
-        if (str < 0 || str > 255) {
-          set_fault(FAULT_CAP_INST);
-          str = 0;
+    if (m.ld8(H_OBSFAULT) & GF_ALIAS) {
+      for (int o = 0; o < 2; o++) {
+        int hn = pl_hand_n(o), dn = pl_deck_n(o);
+        for (int i = 0; i < hn + dn; i++) {
+          int off = i < hn ? hand_ref(o, i) : deck_ref(o, i - hn);
+          int fl = m.ld8(off + 2);
+          if (!(fl & CF_ALIAS)) continue;
+          int slot = m.ld8(off + 3);
+          if (used & (1u << slot)) continue;
+          int str = e_str(slot);
+          if (str < 0 || str > 255) {
+            set_fault(FAULT_CAP_INST);
+            str = 0;
+          }
+          m.st8(off + 2, (fl & ~CF_ALIAS) | CF_STR);
+          m.st8(off + 3, str);
         }
-        m.st8(off + 2, (fl & ~CF_ALIAS) | CF_STR);
-        m.st8(off + 3, str);
       }
     }
-    for (int e = 0; e < NUM_ENT; e++)
-      if (!(used & (1u << e))) m.st8(E_CARD + e, CARD_NONE);
     if (REM_LISTS) rem_collect(used);
     m.st8(H_DEPTH, 0);
   }
@@ -541,33 +546,31 @@ struct Engine {
   // Board.calculate_front_line, board.py:78-92.  `player` is an order; the reference compares
   // Player objects by order (player.py:39-40).
   MSB_HD MSB_NOINLINE void calculate_front_line(int player) {
+    // any(board[y][x] is not None and board[y][x].player == player for x in range(4)) per row
+    auto row_has = [&](int y) {
+      uint32_t row = board_row(y);
+      bool any = false;
+      for (int x = 0; x < 4; x++) {
+        uint32_t s = (row >> (8 * x)) & 0xff;
+        if (s != (uint32_t)SLOT_NONE && e_owner((int)s) == player) any = true;
+      }
+      return any;
+    };
     if (player == local()) {
       int fl = 4;
-      for (int y = 0; y < 5; y++) {
-        bool any = false;
-        for (int x = 0; x < 4; x++) {
-          int s = board_at(y * 4 + x);
-          if (s != SLOT_NONE && e_owner(s) == player) any = true;
-        }
-        if (any) {
+      for (int y = 0; y < 5; y++)
+        if (row_has(y)) {
           fl = y > 1 ? y : 1;
           break;
         }
-      }
       set_pl_front(local(), fl);
     } else {
       int fl = 0;
-      for (int y = 4; y >= 0; y--) {
-        bool any = false;
-        for (int x = 0; x < 4; x++) {
-          int s = board_at(y * 4 + x);
-          if (s != SLOT_NONE && e_owner(s) == player) any = true;
-        }
-        if (any) {
+      for (int y = 4; y >= 0; y--)
+        if (row_has(y)) {
           fl = y < 3 ? y : 3;
           break;
         }
-      }
       set_pl_front(remote(), fl);
     }
   }
@@ -584,9 +587,11 @@ struct Engine {
     const bool asc = (pov == local());
     const int kind = tg_kind(t), side = tg_side(t), limit = tg_limit(t);
     const int types = tg_types(t), xtypes = tg_xtypes(t), status = tg_status(t), xstatus = tg_xstatus(t);
+    uint32_t row = 0;
     for (int i = 0; i < 20; i++) {
       int tile = asc ? i : 19 - i;
-      int e = board_at(tile);
+      if ((i & 3) == 0) row = board_row(tile >> 2);   // four tiles per LDS read
+      int e = (int)((row >> (8 * (tile & 3))) & 0xff);
       if (e == SLOT_NONE) continue;
       int str = e_str(e);
       if (str <= 0) continue;
@@ -1339,14 +1344,16 @@ struct Engine {
   MSB_HD MSB_NOINLINE void flip() {
     set_pl_front(0, 4 - pl_front(0));
     set_pl_front(1, 4 - pl_front(1));
-    for (int t = 0; t < 10; t++) {
-      int a = board_at(t), b = board_at(19 - t);
-      board_put(t, b);
-      board_put(19 - t, a);
-    }
-    for (int t = 0; t < 20; t++) {
-      int s = board_at(t);
-      if (s != SLOT_NONE) m.st8(E_POS + s, t);
+    // 180-degree rotation: new row y = byte-reversed old row 4-y
+    const uint32_t r0 = board_row(0), r1 = board_row(1), r2 = board_row(2), r3 = board_row(3), r4 = board_row(4);
+    for (int y = 0; y < 5; y++) {
+      uint32_t v = y == 0 ? r4 : y == 1 ? r3 : y == 2 ? r2 : y == 3 ? r1 : r0;
+      v = (v >> 24) | ((v >> 8) & 0xff00u) | ((v << 8) & 0xff0000u) | (v << 24);
+      m.st32(OFF_BOARD + 4 * y, v);
+      for (int x = 0; x < 4; x++) {
+        uint32_t s = (v >> (8 * x)) & 0xff;
+        if (s != (uint32_t)SLOT_NONE) m.st8(E_POS + (int)s, y * 4 + x);
+      }
     }
   }
   // Board.to_next_turn, board.py:117-145
@@ -1522,7 +1529,7 @@ struct Engine {
       uint8_t d[DECK_SIZE];
       for (int i = 0; i < DECK_SIZE; i++) {
         d[i] = deck[i];
-        if (g_cards[d[i]].int_id < 0) m.st8(H_OBSFAULT, 1);
+        if (g_cards[d[i]].int_id < 0) m.st8(H_OBSFAULT, m.ld8(H_OBSFAULT) | GF_OBSFAULT);
       }
       for (int i = DECK_SIZE - 1; i >= 1; i--) {  // random.shuffle(self.deck)
         int j = (int)rng_interval((uint32_t)i);

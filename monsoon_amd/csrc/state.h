@@ -54,7 +54,9 @@ constexpr int H_USED = 16;      // u32: entity slots referenced since the start 
 // The game's numpy stream as this record sees it (transient: set when the record is staged for a step, the
 // cursor is written back by the caller): two resident blocks of tempered MT19937 outputs and a cursor.
 constexpr int H_RNGPOS = 20;    // u16 index of the next word, 0..1247 (>= 624 reads the second block)
-constexpr int H_OBSFAULT = 22;  // 1 if a deck holds up01/up02/up03: only then can get_observation raise (card.py:46)
+constexpr int H_OBSFAULT = 22;  // game flags: b0 a deck holds up01/up02/up03 (only then can get_observation raise, card.py:46);
+                                //             b1 a card instance aliasing a board entity exists (b305 has returned to a hand)
+constexpr int GF_OBSFAULT = 1, GF_ALIAS = 2;
 constexpr int H_RNGOVER = 23;   // set when a step wanted more than the two resident blocks
 constexpr int OFF_BOARD = 24;   // 20 x u8 slot
 constexpr int OFF_TRIG = 44;    // TRIG_CAP x u8 (slot | has_source<<7)
