@@ -62,7 +62,7 @@ MSB_HD inline int canon_record(const Engine<M>& g, uint32_t next_u32, uint8_t* o
     p8(g.e_flags(s) & (EF_OWNER | EF_FF));
     p16(g.e_str(s));
     p8(g.card_is_unit(g.e_card(s)) ? g.e_mov(s) : 0);
-    p8(g.m.ld8(E_POS + s));
+    p8(g.m.ld8(OFF_ENT + ENT_SIZE * s + EO_POS));
     for (int k = 0; k < 5; k++) p8(g.e_st(s, k));
   }
   for (int k = 0; k < 4; k++) p8((next_u32 >> (8 * k)) & 0xff);

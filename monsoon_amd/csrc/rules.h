@@ -225,7 +225,7 @@ struct Engine {
   MSB_HD MSB_INL void set_deck_w(int o, int i, double w) { m.stf(deck_wref(o, i), w); }
   // strength attribute of a card instance in hand/deck (see CF_ALIAS / CF_STR in state.h)
   MSB_HD MSB_INL int inst_strength(int card, int fl, int x) const {
-    if (fl & CF_ALIAS) return m.ld16(E_STR + 2 * x);
+    if (fl & CF_ALIAS) return m.ld16(ent(x) + EO_STR);
     if (fl & CF_STR) return x;
     return card < NUM_CARDS ? g_cards[card].strength : 0;
   }
@@ -318,38 +318,39 @@ struct Engine {
   MSB_HD MSB_INL int board_at(int tile) const { return m.ld8(OFF_BOARD + tile); }
   MSB_HD MSB_INL void board_put(int tile, int slot) { m.st8(OFF_BOARD + tile, slot); }
 
-  MSB_HD MSB_INL int e_card(int e) const { return m.ld8(E_CARD + e); }
-  MSB_HD MSB_INL int e_flags(int e) const { return m.ld8(E_FLAGS + e); }
-  MSB_HD MSB_INL int e_owner(int e) const { return m.ld8(E_FLAGS + e) & EF_OWNER; }
-  MSB_HD MSB_INL bool e_ff(int e) const { return (m.ld8(E_FLAGS + e) & EF_FF) != 0; }
+  MSB_HD MSB_INL static int ent(int e) { return OFF_ENT + ENT_SIZE * e; }
+  MSB_HD MSB_INL int e_card(int e) const { return m.ld8(ent(e) + EO_CARD); }
+  MSB_HD MSB_INL int e_flags(int e) const { return m.ld8(ent(e) + EO_FLAGS); }
+  MSB_HD MSB_INL int e_owner(int e) const { return m.ld8(ent(e) + EO_FLAGS) & EF_OWNER; }
+  MSB_HD MSB_INL bool e_ff(int e) const { return (m.ld8(ent(e) + EO_FLAGS) & EF_FF) != 0; }
   MSB_HD MSB_INL void e_set_flag(int e, int bit, bool on) {
-    int f = m.ld8(E_FLAGS + e);
-    m.st8(E_FLAGS + e, on ? (f | bit) : (f & ~bit));
+    int f = m.ld8(ent(e) + EO_FLAGS);
+    m.st8(ent(e) + EO_FLAGS, on ? (f | bit) : (f & ~bit));
   }
-  MSB_HD MSB_INL P e_pos(int e) const { return tile_p(m.ld8(E_POS + e)); }
-  MSB_HD MSB_INL void e_set_pos(int e, P p) { m.st8(E_POS + e, p_tile(p)); }
-  MSB_HD MSB_INL int e_mov(int e) const { return m.ld8(E_MOV + e); }
-  MSB_HD MSB_INL int e_str(int e) const { return m.ld16(E_STR + 2 * e); }
-  MSB_HD MSB_INL void e_set_str(int e, int v) { m.st16(E_STR + 2 * e, v); }
-  MSB_HD MSB_INL int e_dmg(int e) const { return m.ld16(E_DMG + 2 * e); }
-  MSB_HD MSB_INL void e_set_dmg(int e, int v) { m.st16(E_DMG + 2 * e, v); }
-  MSB_HD MSB_INL int e_st(int e, int s) const { return m.ld8(E_ST + s * NUM_ENT + e); }
+  MSB_HD MSB_INL P e_pos(int e) const { return tile_p(m.ld8(ent(e) + EO_POS)); }
+  MSB_HD MSB_INL void e_set_pos(int e, P p) { m.st8(ent(e) + EO_POS, p_tile(p)); }
+  MSB_HD MSB_INL int e_mov(int e) const { return m.ld8(ent(e) + EO_MOV); }
+  MSB_HD MSB_INL int e_str(int e) const { return m.ld16(ent(e) + EO_STR); }
+  MSB_HD MSB_INL void e_set_str(int e, int v) { m.st16(ent(e) + EO_STR, v); }
+  MSB_HD MSB_INL int e_dmg(int e) const { return m.ld16(ent(e) + EO_DMG); }
+  MSB_HD MSB_INL void e_set_dmg(int e, int v) { m.st16(ent(e) + EO_DMG, v); }
+  MSB_HD MSB_INL int e_st(int e, int s) const { return m.ld8(ent(e) + EO_ST + s); }
   MSB_HD MSB_INL void e_st_add(int e, int s) {
-    int c = m.ld8(E_ST + s * NUM_ENT + e);
+    int c = m.ld8(ent(e) + EO_ST + s);
     if (c >= 255) {
       set_fault(FAULT_STATUS_SAT);
       return;
     }
-    m.st8(E_ST + s * NUM_ENT + e, c + 1);
+    m.st8(ent(e) + EO_ST + s, c + 1);
   }
   // list.remove(x) raises ValueError when x is absent
   MSB_HD MSB_INL void e_st_remove(int e, int s) {
-    int c = m.ld8(E_ST + s * NUM_ENT + e);
+    int c = m.ld8(ent(e) + EO_ST + s);
     if (c == 0) {
       set_fault(FAULT_PY_EXCEPTION);
       return;
     }
-    m.st8(E_ST + s * NUM_ENT + e, c - 1);
+    m.st8(ent(e) + EO_ST + s, c - 1);
   }
 
   // ---- card statics (tokens: board.py:298-322) -------------------------------------------------
@@ -445,15 +446,10 @@ struct Engine {
   MSB_HD MSB_NOINLINE int new_entity(int card, int owner, int strength, int movement, bool ff) {
     int e = alloc_entity();
     if (fault()) return e;
-    m.st8(E_CARD + e, card);
-    m.st8(E_FLAGS + e, (owner ? EF_OWNER : 0) | (ff ? EF_FF : 0));
-    m.st8(E_POS + e, 0);
-    m.st8(E_MOV + e, movement);
-    for (int s = 0; s < 5; s++) m.st8(E_ST + s * NUM_ENT + e, 0);
-    m.st8(E_MOVEID + e, 0);
-    m.st8(E_PATHN + e, 0);
-    e_set_str(e, strength);
-    e_set_dmg(e, 0);
+    // card | flags<<8 | pos<<16 | mov<<24 ; st0..st3 = 0 ; st4 = 0, move_id = 0, strength<<16 ; dmg = 0, path_n = 0
+    msb_u32x4 g = {(uint32_t)card | ((uint32_t)((owner ? EF_OWNER : 0) | (ff ? EF_FF : 0)) << 8) | ((uint32_t)(movement & 0xff) << 24),
+                   0u, (uint32_t)(strength & 0xffff) << 16, 0u};
+    m.st128(ent(e), g);
     m.st32(E_PATH + 4 * e, 0);
     if (REM_LISTS) m.st8(E_REM + e, REM_NONE);
     return e;
@@ -514,7 +510,7 @@ struct Engine {
     int r = rem_rec(list, i);
     m.st8(r + 0, e_card(e));
     m.st8(r + 1, e_flags(e));
-    m.st8(r + 2, m.ld8(E_POS + e));
+    m.st8(r + 2, m.ld8(ent(e) + EO_POS));
     m.st8(r + 3, e_mov(e));
     for (int s = 0; s < 5; s++) m.st8(r + 4 + s, e_st(e, s));
     int str = e_str(e);
@@ -536,8 +532,8 @@ struct Engine {
     int str = (int16_t)(m.ld8(r + 9) | (m.ld8(r + 10) << 8));
     int e = new_entity(card, fl & EF_OWNER, str, m.ld8(r + 3), (fl & EF_FF) != 0);
     if (fault()) return e;
-    m.st8(E_FLAGS + e, fl);
-    for (int s = 0; s < 5; s++) m.st8(E_ST + s * NUM_ENT + e, m.ld8(r + 4 + s));
+    m.st8(ent(e) + EO_FLAGS, fl);
+    for (int s = 0; s < 5; s++) m.st8(ent(e) + EO_ST + s, m.ld8(r + 4 + s));
     m.st8(E_REM + e, m.ld8(r + 11));   // the nested memory now belongs to the restored object
     board_set(tile_p(m.ld8(r + 2)), e);
     return e;
@@ -593,9 +589,10 @@ struct Engine {
       if ((i & 3) == 0) row = board_row(tile >> 2);   // four tiles per LDS read
       int e = (int)((row >> (8 * (tile & 3))) & 0xff);
       if (e == SLOT_NONE) continue;
-      int str = e_str(e);
+      const msb_u32x4 g = m.ld128(ent(e));   // the whole entity in one LDS read
+      int str = (int)(int16_t)(g[2] >> 16);
       if (str <= 0) continue;
-      int c = e_card(e);
+      int c = (int)(g[0] & 0xff);
       bool is_unit = card_is_unit(c);
       bool strength_ok = limit == LIMIT_NONE || str <= limit;
       bool ok;
@@ -605,9 +602,11 @@ struct Engine {
         bool xtype_ok = xtypes == 0 || (ty & xtypes) == 0;
         bool hero_ok = !tg_non_hero(t) || !(ty & (1 << UT_HERO));
         int stm = 0;
-        if (status | xstatus)
-          for (int s = 0; s < 5; s++)
-            if (e_st(e, s) > 0) stm |= 1 << s;
+        if (status | xstatus) {
+          for (int s = 0; s < 4; s++)
+            if ((g[1] >> (8 * s)) & 0xff) stm |= 1 << s;
+          if (g[2] & 0xff) stm |= 1 << 4;
+        }
         bool st_ok = status == 0 || (stm & status) != 0;
         bool xst_ok = xstatus == 0 || (stm & xstatus) == 0;
         ok = type_ok && xtype_ok && hero_ok && st_ok && xst_ok && strength_ok && (kind == TK_ANY || kind == TK_UNIT);
@@ -615,7 +614,7 @@ struct Engine {
         ok = strength_ok && (kind == TK_ANY || kind == TK_STRUCTURE);
       }
       if (!ok) continue;
-      int own = e_owner(e);
+      int own = (int)((g[0] >> 8) & EF_OWNER);
       bool side_ok = side == TS_ANY || (side == TS_FRIENDLY && own == pov) || (side == TS_ENEMY && own != pov);
       if (side_ok) out.push(tile_p(tile));
     }
@@ -874,7 +873,7 @@ struct Engine {
   MSB_HD MSB_NOINLINE void destroy(int e, bool src) {
     if (e_is_unit(e)) {
       board_set(e_pos(e), -1);
-      m.st8(E_PATHN + e, 0);
+      m.st8(ent(e) + EO_PATHN, 0);
       e_set_dmg(e, e_str(e));
       if (card_trigger(e_card(e)) == TR_ON_DEATH) {
         push_trigger(e, src);
@@ -987,7 +986,7 @@ struct Engine {
       position = dest;
     }
     m.st32(E_PATH + 4 * e, packed);
-    m.st8(E_PATHN + e, n);
+    m.st8(ent(e) + EO_PATHN, n);
   }
 
   // Unit.move, unit.py:124-203
@@ -1002,8 +1001,8 @@ struct Engine {
     m.st8(H_DEPTH, d);
   }
   MSB_HD MSB_INL void move_body(int e) {
-    int current_id = (m.ld8(E_MOVEID + e) + 1) & 0xff;
-    m.st8(E_MOVEID + e, current_id);
+    int current_id = (m.ld8(ent(e) + EO_MOVEID) + 1) & 0xff;
+    m.st8(ent(e) + EO_MOVEID, current_id);
     if (phase() == PH_TURN_START) {
       if (e_st(e, ST_POISONED) > 0)
         entity_deal_damage(e, 1, false, false);
@@ -1015,13 +1014,13 @@ struct Engine {
         return;
       }
     }
-    if (m.ld8(E_PATHN + e) == 0) return;
+    if (m.ld8(ent(e) + EO_PATHN) == 0) return;
     int trig = e_trigger(e);
     if (trig == TR_BEFORE_MOVING && !e_disabled(e)) run_ability(e, -1, PK_NONE, true);
     if (fault()) return;
     if (e_frozen(e)) return;
     // `for destination in self.path` iterates the list object bound now (fact #5)
-    int n = m.ld8(E_PATHN + e);
+    int n = m.ld8(ent(e) + EO_PATHN);
     uint32_t path = m.ld32(E_PATH + 4 * e);
     int owner = e_owner(e);  // self.player is re-read by the reference; convert() may change it
     for (int i = 0; i < n; i++) {
@@ -1057,7 +1056,7 @@ struct Engine {
           is_attacked = true;
         }
       }
-      if (current_id != m.ld8(E_MOVEID + e)) return;
+      if (current_id != m.ld8(ent(e) + EO_MOVEID)) return;
       if (at(dest) == AT_NONE && e_str(e) > 0) {
         board_set(e_pos(e), -1);
         board_set(dest, e);
@@ -1089,9 +1088,9 @@ struct Engine {
   // Unit.gain_speed, unit.py:277-280
   MSB_HD MSB_INL void gain_speed(int e, int amount) {
     int mv = e_mov(e);
-    m.st8(E_MOV + e, mv + amount);
+    m.st8(ent(e) + EO_MOV, mv + amount);
     set_path(e, e_resolving_play(e));
-    m.st8(E_MOV + e, mv);
+    m.st8(ent(e) + EO_MOV, mv);
   }
   // Unit.command, unit.py:282-289
   MSB_HD MSB_NOINLINE void command(int e) {
@@ -1168,7 +1167,7 @@ struct Engine {
     }
     if (n > 0) {
       m.st32(E_PATH + 4 * e, packed);
-      m.st8(E_PATHN + e, n);
+      m.st8(ent(e) + EO_PATHN, n);
       move(e);
     }
   }
@@ -1352,7 +1351,7 @@ struct Engine {
       m.st32(OFF_BOARD + 4 * y, v);
       for (int x = 0; x < 4; x++) {
         uint32_t s = (v >> (8 * x)) & 0xff;
-        if (s != (uint32_t)SLOT_NONE) m.st8(E_POS + (int)s, y * 4 + x);
+        if (s != (uint32_t)SLOT_NONE) m.st8(ent((int)s) + EO_POS, y * 4 + x);
       }
     }
   }
@@ -1380,7 +1379,7 @@ struct Engine {
     for (int i = 0; i < ns; i++) {
       int s = snap.get(i);
       // structure.is_at_turn_start: token structures and b001 run the empty base ability
-      if (card_trigger(e_card(s)) == TR_TURN_START) run_ability(s, -1, m.ld8(E_POS + s) /*unused*/, true);
+      if (card_trigger(e_card(s)) == TR_TURN_START) run_ability(s, -1, m.ld8(ent(s) + EO_POS) /*unused*/, true);
       if (fault()) return;
     }
     snap = get_targets(ncp, mk_tgt(TK_UNIT, TS_FRIENDLY), PK_NONE);
@@ -1510,7 +1509,7 @@ struct Engine {
     m.st64(H_RNGNXT, rn);
     m.st16(H_RNGPOS, (int)rp);
     for (int t = 0; t < 20; t++) board_put(t, SLOT_NONE);
-    for (int e = 0; e < NUM_ENT; e++) m.st8(E_CARD + e, CARD_NONE);
+    for (int e = 0; e < NUM_ENT; e++) m.st8(ent(e) + EO_CARD, CARD_NONE);
     if (REM_LISTS)
       for (int e = 0; e < NUM_ENT; e++) m.st8(E_REM + e, REM_NONE);
     for (int i = 0; i < 4; i++) {

@@ -97,24 +97,26 @@ static_assert((OFF_PL % 8) == 0 && (PL_SIZE % 8) == 0, "f64 alignment");
 // position attribute, which matters for list.remove's equality (structure.py:18-19).
 constexpr int CF_SINGLE_USE = 1, CF_FF = 2, CF_STR = 4, CF_ALIAS = 8;
 
-// ---- entities (field arrays) ------------------------------------------------------------------
-constexpr int OFF_ENT = OFF_PL + 2 * PL_SIZE;
-constexpr int E_CARD = OFF_ENT;                 // u8[NUM_ENT] card index (CARD_NONE = free)
-constexpr int E_FLAGS = E_CARD + NUM_ENT;       // u8 b0 owner order, b1 fixedly_forward, b2 resolving_play
-constexpr int E_POS = E_FLAGS + NUM_ENT;        // u8 recorded position y*4+x
-constexpr int E_MOV = E_POS + NUM_ENT;          // u8 movement
-constexpr int E_ST = E_MOV + NUM_ENT;           // u8[5][NUM_ENT] status multiset counts
-constexpr int E_MOVEID = E_ST + 5 * NUM_ENT;    // u8 move_id (mod 256)
-constexpr int E_PATHN = E_MOVEID + NUM_ENT;     // u8 len(path)
-constexpr int E_STR = (E_PATHN + NUM_ENT + 1) & ~1;   // i16 strength
-constexpr int E_DMG = E_STR + 2 * NUM_ENT;      // i16 damage_taken
-constexpr int E_PATH = (E_DMG + 2 * NUM_ENT + 3) & ~3;  // u32 packed path (PATH_CAP bytes)
+// ---- entities: one 16-byte granule per slot (a whole entity is ONE ds_read_b128 / ds_write_b128) -----
+constexpr int OFF_ENT = (OFF_PL + 2 * PL_SIZE + 15) & ~15;
+constexpr int ENT_SIZE = 16;
+constexpr int EO_CARD = 0;      // u8 card index (CARD_NONE = never used)
+constexpr int EO_FLAGS = 1;     // u8 b0 owner order, b1 fixedly_forward, b2 resolving_play, b3 is_single_use
+constexpr int EO_POS = 2;       // u8 recorded position y*4+x
+constexpr int EO_MOV = 3;       // u8 movement
+constexpr int EO_ST = 4;        // u8[5] status multiset counts (FROZEN, POISONED, CONFUSED, DISABLED, VITALIZED)
+constexpr int EO_MOVEID = 9;    // u8 move_id (mod 256)
+constexpr int EO_STR = 10;      // i16 strength
+constexpr int EO_DMG = 12;      // i16 damage_taken
+constexpr int EO_PATHN = 14;    // u8 len(path)
+constexpr int E_PATH = OFF_ENT + ENT_SIZE * NUM_ENT;   // u32[NUM_ENT] packed path (PATH_CAP bytes)
 constexpr int E_REM = E_PATH + 4 * NUM_ENT;                       // u8[NUM_ENT]: b005's list id (REM_NONE = [])
 constexpr int OFF_REM = (E_REM + (REM_LISTS ? NUM_ENT : 0) + 3) & ~3; // REM_LISTS x {n, used, pad2, REM_PER_LIST x REM_REC}
 constexpr int REM_LIST_BYTES = 4 + REM_PER_LIST * REM_REC;
 constexpr int STATE_BYTES = (OFF_REM + REM_LISTS * REM_LIST_BYTES + 15) & ~15;   // whole 16-byte granules
 constexpr int STATE_WORDS = STATE_BYTES / 4;
 constexpr int EF_OWNER = 1, EF_FF = 2, EF_RESOLVING_PLAY = 4, EF_SINGLE_USE = 8;
+typedef uint32_t msb_u32x4 __attribute__((vector_size(16)));
 
 // ---- accessors ----------------------------------------------------------------------------------
 // Host / flat: the record is a contiguous byte array.
@@ -130,6 +132,13 @@ struct FlatMem {
   MSB_HD MSB_INL void stf(int o, double v) { *(double*)(p + o) = v; }
   MSB_HD MSB_INL uint64_t ld64(int o) const { return *(const uint64_t*)(p + o); }
   MSB_HD MSB_INL void st64(int o, uint64_t v) { *(uint64_t*)(p + o) = v; }
+  // the host record is only 8-byte aligned: no aligned vector moves
+  MSB_HD MSB_INL msb_u32x4 ld128(int o) const {
+    msb_u32x4 v;
+    __builtin_memcpy(&v, p + o, 16);
+    return v;
+  }
+  MSB_HD MSB_INL void st128(int o, msb_u32x4 v) { __builtin_memcpy(p + o, &v, 16); }
 };
 
 #if defined(__HIPCC__)
@@ -161,6 +170,8 @@ struct LaneMem {   // this lane's private record among LANES interleaved ones
   MSB_HD MSB_INL static void stf(int o, double v) { *(MSB_AS_LDS double*)b(o) = v; }
   MSB_HD MSB_INL static uint64_t ld64(int o) { return *(MSB_AS_LDS const uint64_t*)b(o); }
   MSB_HD MSB_INL static void st64(int o, uint64_t v) { *(MSB_AS_LDS uint64_t*)b(o) = v; }
+  MSB_HD MSB_INL static msb_u32x4 ld128(int o) { return *(MSB_AS_LDS const msb_u32x4*)b(o); }
+  MSB_HD MSB_INL static void st128(int o, msb_u32x4 v) { *(MSB_AS_LDS msb_u32x4*)b(o) = v; }
 };
 template <int BASE>
 struct SharedMem {   // one contiguous record read by every lane of the wave (LDS broadcast)
@@ -175,6 +186,8 @@ struct SharedMem {   // one contiguous record read by every lane of the wave (LD
   MSB_HD MSB_INL static void stf(int o, double v) { *(MSB_AS_LDS double*)b(o) = v; }
   MSB_HD MSB_INL static uint64_t ld64(int o) { return *(MSB_AS_LDS const uint64_t*)b(o); }
   MSB_HD MSB_INL static void st64(int o, uint64_t v) { *(MSB_AS_LDS uint64_t*)b(o) = v; }
+  MSB_HD MSB_INL static msb_u32x4 ld128(int o) { return *(MSB_AS_LDS const msb_u32x4*)b(o); }
+  MSB_HD MSB_INL static void st128(int o, msb_u32x4 v) { *(MSB_AS_LDS msb_u32x4*)b(o) = v; }
 };
 #endif
 

@@ -26,7 +26,7 @@ using namespace msb;
 namespace {
 
 struct Game {
-  alignas(8) uint8_t st[STATE_BYTES];
+  alignas(16) uint8_t st[STATE_BYTES];
   uint32_t mt[MT_N];
   uint32_t out[2][MT_N];
   int cur;        // which of out[] is the current block
