@@ -369,10 +369,18 @@ struct Engine {
     int t = c - TOKEN_UNIT_BASE;                                   // "f" + str(t).zfill(3) parsed as hex
     return 0x4000 + (t < 10 ? t : 0x10 + (t - 10));
   }
-  MSB_HD MSB_INL bool e_is_unit(int e) const { return card_is_unit(e_card(e)); }
+  // static facts of the entity's card, cached in the entity record when it is created (no card-table
+  // load -- a global-memory round trip -- inside the selectors and the movement loop)
+  MSB_HD MSB_INL int e_kind(int e) const { return m.ld8(ent(e) + EO_KIND); }
+  MSB_HD MSB_INL bool e_is_unit(int e) const { return (e_kind(e) & EK_UNIT) != 0; }
+  MSB_HD MSB_INL bool e_has_ability(int e) const { return (e_kind(e) & EK_ABILITY) != 0; }
+  MSB_HD MSB_INL int e_card_trigger(int e) const { return ((e_kind(e) >> 2) & 15) - 1; }   // card_trigger(e_card(e))
   MSB_HD MSB_INL int e_trigger(int e) const {  // Unit.trigger; Structures have no .trigger attribute
-    int c = e_card(e);
-    return card_is_unit(c) ? card_trigger(c) : TR_NONE;
+    int k = e_kind(e);
+    return (k & EK_UNIT) ? ((k >> 2) & 15) - 1 : TR_NONE;
+  }
+  MSB_HD MSB_INL int kind_byte(int card) const {
+    return (card_is_unit(card) ? EK_UNIT : 0) | (card_has_ability(card) ? EK_ABILITY : 0) | ((card_trigger(card) + 1) << 2);
   }
   MSB_HD MSB_INL bool e_disabled(int e) const { return e_st(e, ST_DISABLED) > 0; }
   MSB_HD MSB_INL bool e_confused(int e) const { return e_st(e, ST_CONFUSED) > 0; }
@@ -448,7 +456,7 @@ struct Engine {
     if (fault()) return e;
     // card | flags<<8 | pos<<16 | mov<<24 ; st0..st3 = 0 ; st4 = 0, move_id = 0, strength<<16 ; dmg = 0, path_n = 0
     msb_u32x4 g = {(uint32_t)card | ((uint32_t)((owner ? EF_OWNER : 0) | (ff ? EF_FF : 0)) << 8) | ((uint32_t)(movement & 0xff) << 24),
-                   0u, (uint32_t)(strength & 0xffff) << 16, 0u};
+                   0u, (uint32_t)(strength & 0xffff) << 16, (uint32_t)kind_byte(card) << 24};
     m.st128(ent(e), g);
     m.st32(E_PATH + 4 * e, 0);
     if (REM_LISTS) m.st8(E_REM + e, REM_NONE);
@@ -593,11 +601,11 @@ struct Engine {
       int str = (int)(int16_t)(g[2] >> 16);
       if (str <= 0) continue;
       int c = (int)(g[0] & 0xff);
-      bool is_unit = card_is_unit(c);
+      bool is_unit = ((g[3] >> 24) & EK_UNIT) != 0;
       bool strength_ok = limit == LIMIT_NONE || str <= limit;
       bool ok;
       if (is_unit) {
-        int ty = card_types(c);
+        int ty = (types | xtypes | (tg_non_hero(t) ? 1 : 0)) ? card_types(c) : 0;   // table lookup only for type filters
         bool type_ok = types == 0 || (ty & types) != 0;
         bool xtype_ok = xtypes == 0 || (ty & xtypes) == 0;
         bool hero_ok = !tg_non_hero(t) || !(ty & (1 << UT_HERO));
@@ -824,7 +832,7 @@ struct Engine {
   }
   // entity.activate_ability(...) as called by the engine: wrapped iff the class overrides it.
   MSB_HD MSB_INL void activate(int e, int pos_pk, bool src) {
-    if (card_has_ability(e_card(e))) run_ability(e, -1, pos_pk, src);
+    if (e_has_ability(e)) run_ability(e, -1, pos_pk, src);
   }
 
   // ------------------------------------------------------------------------------------------
@@ -846,7 +854,7 @@ struct Engine {
     e_set_str(e, s);
     if (!pending && s <= 0) {
       destroy(e, src);
-    } else if (e_is_unit(e) && card_trigger(e_card(e)) == TR_AFTER_SURVIVING && s > 0) {
+    } else if (e_trigger(e) == TR_AFTER_SURVIVING && s > 0) {
       push_trigger(e, src);
       pop_trigger();
     }
@@ -875,7 +883,7 @@ struct Engine {
       board_set(e_pos(e), -1);
       m.st8(ent(e) + EO_PATHN, 0);
       e_set_dmg(e, e_str(e));
-      if (card_trigger(e_card(e)) == TR_ON_DEATH) {
+      if (e_card_trigger(e) == TR_ON_DEATH) {
         push_trigger(e, src);
         pop_trigger();
       }
@@ -915,7 +923,7 @@ struct Engine {
     if (need_unit(e)) e_st_remove(e, ST_CONFUSED);
   }
   MSB_HD MSB_INL void disable(int e) {  // unit.py:269-271: only classes that override the ability
-    if (need_unit(e) && card_has_ability(e_card(e))) e_st_add(e, ST_DISABLED);
+    if (need_unit(e) && e_has_ability(e)) e_st_add(e, ST_DISABLED);
   }
 
   // ------------------------------------------------------------------------------------------
@@ -1043,7 +1051,7 @@ struct Engine {
         target = at(dest);
         if (target != AT_NONE) {
           int target_strength_cached = e_str(target);
-          bool target_pending = e_is_unit(target) && card_trigger(e_card(target)) == TR_ON_DEATH && !e_disabled(target);
+          bool target_pending = e_trigger(target) == TR_ON_DEATH && !e_disabled(target);
           bool local_pending = trig == TR_ON_DEATH && !e_disabled(e);
           entity_deal_damage(target, e_str(e), target_pending, false);
           if (fault()) return;
@@ -1074,7 +1082,7 @@ struct Engine {
     e_set_flag(e, EF_RESOLVING_PLAY, true);
     board_set(position, e);
     set_path(e, true);
-    if (card_trigger(e_card(e)) == TR_ON_PLAY) run_ability(e, -1, PK_NONE, true);
+    if (e_card_trigger(e) == TR_ON_PLAY) run_ability(e, -1, PK_NONE, true);
     if (fault()) return;
     move(e);
     e_set_flag(e, EF_RESOLVING_PLAY, false);
@@ -1082,7 +1090,7 @@ struct Engine {
   // Structure.play, structure.py:45-50
   MSB_HD MSB_NOINLINE void structure_play(int e, P position) {
     board_set(position, e);
-    if (card_trigger(e_card(e)) == TR_ON_PLAY) run_ability(e, -1, PK_NONE, true);
+    if (e_card_trigger(e) == TR_ON_PLAY) run_ability(e, -1, PK_NONE, true);
   }
   MSB_HD MSB_INL bool e_resolving_play(int e) const { return (e_flags(e) & EF_RESOLVING_PLAY) != 0; }
   // Unit.gain_speed, unit.py:277-280
@@ -1379,7 +1387,7 @@ struct Engine {
     for (int i = 0; i < ns; i++) {
       int s = snap.get(i);
       // structure.is_at_turn_start: token structures and b001 run the empty base ability
-      if (card_trigger(e_card(s)) == TR_TURN_START) run_ability(s, -1, m.ld8(ent(s) + EO_POS) /*unused*/, true);
+      if (e_card_trigger(s) == TR_TURN_START) run_ability(s, -1, m.ld8(ent(s) + EO_POS) /*unused*/, true);
       if (fault()) return;
     }
     snap = get_targets(ncp, mk_tgt(TK_UNIT, TS_FRIENDLY), PK_NONE);

@@ -109,6 +109,8 @@ constexpr int EO_MOVEID = 9;    // u8 move_id (mod 256)
 constexpr int EO_STR = 10;      // i16 strength
 constexpr int EO_DMG = 12;      // i16 damage_taken
 constexpr int EO_PATHN = 14;    // u8 len(path)
+constexpr int EO_KIND = 15;     // u8 static card facts cached at creation: b0 is Unit, b1 overrides activate_ability, b2-5 trigger+1
+constexpr int EK_UNIT = 1, EK_ABILITY = 2;
 constexpr int E_PATH = OFF_ENT + ENT_SIZE * NUM_ENT;   // u32[NUM_ENT] packed path (PATH_CAP bytes)
 constexpr int E_REM = E_PATH + 4 * NUM_ENT;                       // u8[NUM_ENT]: b005's list id (REM_NONE = [])
 constexpr int OFF_REM = (E_REM + (REM_LISTS ? NUM_ENT : 0) + 3) & ~3; // REM_LISTS x {n, used, pad2, REM_PER_LIST x REM_REC}
