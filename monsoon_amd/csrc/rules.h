@@ -226,7 +226,7 @@ struct Engine {
   // strength attribute of a card instance in hand/deck (see CF_ALIAS / CF_STR in state.h)
   MSB_HD MSB_INL int inst_strength(int card, int fl, int x) const {
     if (fl & CF_ALIAS) return m.ld16(ent(x) + EO_STR);
-    if (fl & CF_STR) return x;
+    if (fl & (CF_STR | CF_XBASE)) return x;
     return card < NUM_CARDS ? g_cards[card].strength : 0;
   }
   // list primitives -----------------------------------------------------------------------------
@@ -1554,8 +1554,8 @@ struct Engine {
         int r = deck_ref(o, i);
         m.st8(r, d[i]);
         m.st8(r + 1, g_cards[d[i]].cost);
-        m.st8(r + 2, g_cards[d[i]].ff ? CF_FF : 0);
-        m.st8(r + 3, 0);
+        m.st8(r + 2, (g_cards[d[i]].ff ? CF_FF : 0) | CF_XBASE | (g_cards[d[i]].kind == KIND_SPELL ? CF_SPELL : 0));
+        m.st8(r + 3, g_cards[d[i]].strength);
         set_deck_w(o, i, w);
       }
       m.st8(pl(o, P_DECK_N), DECK_SIZE);

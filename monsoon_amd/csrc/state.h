@@ -96,6 +96,9 @@ static_assert((OFF_PL % 8) == 0 && (PL_SIZE % 8) == 0, "f64 alignment");
 // on the board (CF_ALIAS) and keeps its last strength in x afterwards (CF_STR).  Both kinds have a
 // position attribute, which matters for list.remove's equality (structure.py:18-19).
 constexpr int CF_SINGLE_USE = 1, CF_FF = 2, CF_STR = 4, CF_ALIAS = 8;
+// b4: x holds the card's printed strength (fresh card: cached so that features/observation need no card-table load);
+// b5: the card is a Spell (observed strength -1, hand-quality strength 0)
+constexpr int CF_XBASE = 16, CF_SPELL = 32;
 
 // ---- entities: one 16-byte granule per slot (a whole entity is ONE ds_read_b128 / ds_write_b128) -----
 constexpr int OFF_ENT = (OFF_PL + 2 * PL_SIZE + 15) & ~15;
