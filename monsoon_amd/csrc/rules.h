@@ -403,7 +403,7 @@ struct Engine {
   }
 
   // A free entity slot: not on the board and not referenced since the step began.
-  MSB_HD MSB_NOINLINE int alloc_entity() {
+  MSB_HD MSB_INL int alloc_entity() {
     uint32_t used = m.ld32(H_USED);
     for (int e = 0; e < NUM_ENT; e++) {
       if (!(used & (1u << e))) {
@@ -418,7 +418,7 @@ struct Engine {
   // (no live Python reference survives a step).
   // the 20 board bytes as five 32-bit rows (row y = tiles 4y..4y+3, x in byte x): one LDS read per row
   MSB_HD MSB_INL uint32_t board_row(int y) const { return m.ld32(OFF_BOARD + 4 * y); }
-  MSB_HD MSB_NOINLINE void begin_step() {
+  MSB_HD MSB_INL void begin_step() {
     uint32_t used = 0;
     for (int y = 0; y < 5; y++) {
       uint32_t row = board_row(y);
@@ -1078,7 +1078,7 @@ struct Engine {
   }
 
   // Unit.play, unit.py:66-76
-  MSB_HD MSB_NOINLINE void unit_play(int e, P position) {
+  MSB_HD MSB_INL void unit_play(int e, P position) {
     e_set_flag(e, EF_RESOLVING_PLAY, true);
     board_set(position, e);
     set_path(e, true);
@@ -1088,7 +1088,7 @@ struct Engine {
     e_set_flag(e, EF_RESOLVING_PLAY, false);
   }
   // Structure.play, structure.py:45-50
-  MSB_HD MSB_NOINLINE void structure_play(int e, P position) {
+  MSB_HD MSB_INL void structure_play(int e, P position) {
     board_set(position, e);
     if (e_card_trigger(e) == TR_ON_PLAY) run_ability(e, -1, PK_NONE, true);
   }
@@ -1269,7 +1269,7 @@ struct Engine {
     if (need > 0) draw(o, need);
   }
   // Player.discard, player.py:57-66 (reweight: w*1.6+100 for every deck card)
-  MSB_HD MSB_NOINLINE void discard(int o, int hand_index) {
+  MSB_HD MSB_INL void discard(int o, int hand_index) {
     int n = pl_deck_n(o);
     for (int i = 0; i < n; i++) set_deck_w(o, i, deck_w(o, i) * 1.6 + 100);   // per list position
     uint32_t target = hand_handle(o, hand_index);
@@ -1464,20 +1464,18 @@ struct Engine {
     int result = 0;
     begin_step();
     int lo = local();
-    if (action < 64) {
-      int ci = action >> 4, idx = action & 15;
-      P pos{idx & 3, 4 - (idx >> 2)};
-      set_pl_mana(lo, pl_mana(lo) - hand_cost(lo, ci));
-      player_play(lo, ci, pos, true);
-    } else if (action < 148) {
-      int ci = (action - 64) / 21, idx = (action - 64) % 21;
-      // The countdown executes at the idx-th tile of y=4..0,x=0..3 -- one tile after the one
-      // Action.to_int encoded (fact #2); idx==20 falls off the loop: nothing happens at all.
+    if (action < 148) {
+      // PLACE: card = a//16, tile = a%16 over y=4..1,x=0..3.  USE: card = (a-64)//21, idx = (a-64)%21; the
+      // countdown executes at the idx-th tile of y=4..0,x=0..3 -- one tile after the one Action.to_int
+      // encoded (fact #2); idx==20 falls off the loop: nothing happens at all.
+      bool place = action < 64;
+      int ci = place ? action >> 4 : (action - 64) / 21;
+      int idx = place ? action & 15 : (action - 64) % 21;
       if (idx < 20) {
         P pos{idx & 3, 4 - (idx >> 2)};
-        bool targeted = g_cards[hand_card(lo, ci)].tgt.has != 0;
+        bool has_pos = place || g_cards[hand_card(lo, ci)].tgt.has != 0;
         set_pl_mana(lo, pl_mana(lo) - hand_cost(lo, ci));
-        player_play(lo, ci, pos, targeted);
+        player_play(lo, ci, pos, has_pos);
       }
     } else if (action < 152) {
       cycle(lo, action - 148);
