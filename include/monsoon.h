@@ -73,8 +73,13 @@ int monsoon_reset(monsoon_t* h, int32_t n, const uint32_t* seeds, const uint8_t*
 int monsoon_legal_mask(monsoon_t* h, uint64_t* out);
 
 /* Stormbound.step (games/stormbound.py:318-373) for every game; actions[n] must be legal
- * (actions[i] = 255 leaves game i untouched).  reward[n] in {0,1}, done[n], fault[n] (0 = none). */
+ * (PASS = 155 is always accepted, as the reference's scripted bot relies on; actions[i] = 255 leaves game i untouched).  reward[n] in {0,1}, done[n], fault[n] (0 = none). */
 int monsoon_step(monsoon_t* h, const uint8_t* actions, int8_t* reward, uint8_t* done, uint8_t* fault);
+
+/* Stormbound.expert_action (games/stormbound.py:563-637), the reference's scripted opponent, for every game:
+ * out_action[n] (may be PASS while plays remain -- that is how the bot ends a turn); fault[n] (may be NULL)
+ * is non-zero where the reference would raise.  Draws from the game's own stream, like the reference. */
+int monsoon_expert_action(monsoon_t* h, uint8_t* out_action, uint8_t* fault);
 
 /* Stormbound.get_observation (games/stormbound.py:400-526): out[n][27][5][4] int32.
  * raises[n] = 1 where the reference would raise (int(card) on up01/up02/up03, card.py:46). */

@@ -237,7 +237,9 @@ __global__ void __launch_bounds__(64) k_step(DevBuffers b, int n, const uint8_t*
   api_load(b.state + (size_t)g * SW);
   msb_u64x4 mask = e.legal_mask_v();
   uint64_t word = a < 64 ? mask[0] : (a < 128 ? mask[1] : mask[2]);
-  if (a >= 156 || !((word >> (a & 63)) & 1)) {
+  // PASS (155) is always accepted: the reference's step executes it whenever asked, and its own scripted bot
+  // ends a turn with PASS while plays remain (games/stormbound.py:637)
+  if (a >= 156 || (a != 155 && !((word >> (a & 63)) & 1))) {
     illegal[g] = 1;
     return;
   }
@@ -253,6 +255,20 @@ __global__ void __launch_bounds__(64) k_step(DevBuffers b, int n, const uint8_t*
   if (e.fault()) m.fault = (uint8_t)e.fault();
   b.meta[g] = m;
   api_store(b.state + (size_t)g * SW);
+}
+
+// Stormbound.expert_action for every game (draws from the game's stream, so the cursor is committed)
+__global__ void __launch_bounds__(64) k_expert(DevBuffers b, int n, uint8_t* out_action, uint8_t* fault) {
+  API_GAME_INDEX();
+  ApiEngine e;
+  api_load(b.state + (size_t)g * SW);
+  GameMeta m = b.meta[g];
+  attach_rng(e, b, g, m.rng);
+  int a = e.expert_action();
+  out_action[g] = (uint8_t)a;
+  fault[g] = (uint8_t)e.fault();
+  lane_commit_rng(b, g, m, e.rng_pos());
+  b.meta[g] = m;
 }
 
 __global__ void __launch_bounds__(64) k_observe(DevBuffers b, int n, int32_t* out, uint8_t* raises) {
@@ -760,6 +776,22 @@ int monsoon_step(monsoon_t* h, const uint8_t* actions, int8_t* reward, uint8_t* 
   if (reward) memcpy(reward, host.data(), n);
   if (done) memcpy(done, host.data() + n, n);
   if (fault) memcpy(fault, host.data() + 2 * (size_t)n, n);
+  return MONSOON_OK;
+}
+
+int monsoon_expert_action(monsoon_t* h, uint8_t* out_action, uint8_t* fault) {
+  int rc = check_ready(h);
+  if (rc) return rc;
+  if (!out_action) return MONSOON_ERR_ARG;
+  int n = h->n;
+  uint8_t* d = h->d_bytes;
+  hipLaunchKernelGGL(k_expert, dim3((n + API_LANES - 1) / API_LANES), dim3(64), API_LDS_BYTES, h->stream, h->b, n, d, d + n);
+  HIP_TRY(h, hipGetLastError());
+  std::vector<uint8_t> host(2 * (size_t)n);
+  HIP_TRY(h, hipMemcpyAsync(host.data(), d, 2 * (size_t)n, hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  memcpy(out_action, host.data(), n);
+  if (fault) memcpy(fault, host.data() + n, n);
   return MONSOON_OK;
 }
 

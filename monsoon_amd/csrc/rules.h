@@ -1505,6 +1505,102 @@ struct Engine {
     return result;
   }
 
+  // Stormbound.expert_action, games/stormbound.py:563-637: the reference's scripted opponent.  Draws from
+  // the GAME's stream (self.random).  May return PASS while plays are still legal -- that is how it ends a turn.
+  MSB_HD MSB_NOINLINE int expert_action() {
+    msb_u64x4 lm = legal_mask_v();
+    int lo = local();
+    int hn = pl_hand_n(lo), mana = pl_mana(lo);
+    if ((lm[2] >> (148 - 128)) & 0xf) {   // any REPLACE offered
+      int max_cost = -1;
+      for (int i = 0; i < hn; i++) max_cost = hand_cost(lo, i) > max_cost ? hand_cost(lo, i) : max_cost;
+      if (max_cost > mana) {
+        PList idx;
+        idx.clear();
+        for (int i = 0; i < hn; i++)
+          if (hand_cost(lo, i) == max_cost) idx.push_raw(i);
+        return 148 + idx.get(choice_index(idx.n()));
+      }
+    }
+    PList playable;
+    playable.clear();
+    for (int i = 0; i < 4; i++) {
+      // any x in [16i, 16i+15] or [21i+64, 21i+84]
+      bool any = false;
+      for (int a = 16 * i; a <= 16 * i + 15 && !any; a++) any = (lm[0] >> a) & 1;
+      for (int a = 21 * i + 64; a <= 21 * i + 84 && !any; a++) any = a < 128 ? ((lm[1] >> (a - 64)) & 1) : ((lm[2] >> (a - 128)) & 1);
+      if (any) playable.push_raw(i);
+    }
+    if (playable.n() > 0) {
+      // cards whose cost equals the current mana, else the cheapest ones; random among them
+      bool exact = false;
+      int min_cost = 1 << 20;
+      for (int k = 0; k < playable.n(); k++) {
+        int c = hand_cost(lo, playable.get(k));
+        if (c == mana) exact = true;
+        if (c < min_cost) min_cost = c;
+      }
+      int want = exact ? mana : min_cost;
+      PList pick;
+      pick.clear();
+      for (int k = 0; k < playable.n(); k++)
+        if (hand_cost(lo, playable.get(k)) == want) pick.push_raw(k);
+      int index = playable.get(pick.get(choice_index(pick.n())));
+      int card = hand_card(lo, index);
+      const CardInfo& ci = g_cards[card];
+      PList enemies = get_targets(cp(), mk_tgt(TK_UNIT, TS_ENEMY), PK_NONE);
+      PList bbe;   // base_bordering_enemies
+      bbe.clear();
+      for (int k = 0; k < enemies.n(); k++)
+        if (enemies.at(k).y == 4) bbe.push_raw(enemies.get(k));
+      if (ci.kind == KIND_SPELL) {
+        if (!ci.tgt.has) return 64 + 21 * index;
+        PList t = get_targets(cp(), mk_tgt(ci.tgt), PK_NONE);
+        if (t.n() == 0) {
+          set_fault(FAULT_PY_EXCEPTION);   // random.choice([]) raises
+          return 155;
+        }
+        P p = choice_point(t);
+        return p_valid(p) ? 65 + 21 * index + (4 - p.y) * 4 + p.x : 155;
+      } else if (ci.kind == KIND_UNIT && bbe.n() > 0) {
+        PList cand;
+        cand.clear();
+        for (int k = 0; k < bbe.n(); k++) {
+          P en = bbe.at(k);
+          if (en.x > 0 && at(P{en.x - 1, en.y}) == AT_NONE)
+            cand.push(P{en.x - 1, en.y});
+          else if (en.x < 3 && at(P{en.x + 1, en.y}) == AT_NONE)
+            cand.push(P{en.x + 1, en.y});
+        }
+        if (cand.n() > 0) {
+          P p = choice_point(cand);
+          return p.y >= 1 ? 16 * index + (4 - p.y) * 4 + p.x : 155;
+        }
+      } else {
+        int fl = pl_front(lo);
+        PList cand;
+        cand.clear();
+        for (int x = 0; x < 4; x++)
+          if (at(P{x, fl}) == AT_NONE) cand.push(P{x, fl});
+        for (int k = 0; k < enemies.n(); k++) {
+          P en = enemies.at(k);
+          if (en.x > 0 && en.y >= fl && at(P{en.x - 1, en.y}) == AT_NONE)
+            cand.push(P{en.x - 1, en.y});
+          else if (en.x < 3 && en.y >= fl && at(P{en.x + 1, en.y}) == AT_NONE)
+            cand.push(P{en.x + 1, en.y});
+          else if (en.y < 4 && en.y + 1 >= fl && at(P{en.x, en.y + 1}) == AT_NONE)
+            cand.push(P{en.x, en.y + 1});
+        }
+        if (cand.n() > 0) {
+          P p = choice_point(cand);
+          return p.y >= 1 ? 16 * index + (4 - p.y) * 4 + p.x : 155;
+        }
+      }
+    }
+    if (m.ld8(H_RNGOVER)) set_fault(FAULT_RNG_OVERRUN);
+    return 155;
+  }
+
   // Game construction: Stormbound.__init__ / Player.__init__ (games/stormbound.py:293-304,
   // player.py:13-37).  deck0/deck1: 12 card indices in constructor order.
   MSB_HD MSB_NOINLINE void init_game(const uint8_t* deck0, const uint8_t* deck1, int faction0, int faction1) {

@@ -75,6 +75,13 @@ class BatchEngine:
         self._ck(self.lib.monsoon_step(self.h, _ptr(actions), _ptr(reward), _ptr(done), _ptr(fault)), "monsoon_step")
         return reward, done, fault
 
+    def expert_action(self):
+        """Stormbound.expert_action for every game (consumes the games' streams)."""
+        action = np.zeros(self.n, dtype=np.uint8)
+        fault = np.zeros(self.n, dtype=np.uint8)
+        self._ck(self.lib.monsoon_expert_action(self.h, _ptr(action), _ptr(fault)), "monsoon_expert_action")
+        return action, fault
+
     def observe(self):
         out = np.zeros((self.n, 27, 5, 4), dtype=np.int32)
         raises = np.zeros(self.n, dtype=np.uint8)

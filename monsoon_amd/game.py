@@ -80,6 +80,13 @@ class Stormbound:
             raise StepFault(int(fault[0]), action)
         return self.get_observation(), int(reward[0]), bool(done[0])
 
+    def expert_action(self):
+        """games/stormbound.py:563-637 (draws from the game's stream)."""
+        action, fault = self._eng.expert_action()
+        if fault[0]:
+            raise StepFault(int(fault[0]), "expert_action")
+        return int(action[0])
+
     def state_record(self):
         return self._eng.export(0)
 
@@ -127,7 +134,7 @@ class Game:
         self.env._eng.close()
 
     def expert_agent(self):
-        raise NotImplementedError("Stormbound.expert_action (games/stormbound.py:563-637) is a 'next' row (SURVEY §8f)")
+        return self.env.expert_action()             # games/stormbound.py:227-235
 
     def action_to_string(self, action_number):
         return action_to_string(action_number)

@@ -179,6 +179,16 @@ int orc_step(void* h, int gi, int action, int* reward, int* done) {
   return f;
 }
 
+// Stormbound.expert_action (consumes the game's stream).  Returns the action; *fault_out the fault code.
+int orc_expert_action(void* h, int gi, int* fault_out) {
+  Game& g = ((Oracle*)h)->games[gi];
+  Engine<FlatMem> e = engine(g);
+  int a = e.expert_action();
+  if (fault_out) *fault_out = e.fault();
+  commit_rng(g, e);
+  return a;
+}
+
 int orc_observe(void* h, int gi, int32_t* out540) {
   Game& g = ((Oracle*)h)->games[gi];
   Engine<FlatMem> e = engine(g);

@@ -26,7 +26,7 @@ LIB = ctypes.CDLL(os.path.join(H.REPO, "oracle", "liboracle_ext.so" if EXT else 
 LIB.orc_create.restype = ctypes.c_void_p
 LIB.orc_canon_hash.restype = ctypes.c_uint64
 for name in ("orc_reset", "orc_legal", "orc_step", "orc_observe", "orc_features", "orc_canon", "orc_destroy",
-             "orc_canon_hash", "orc_have_winner", "orc_to_play", "orc_decide"):
+             "orc_canon_hash", "orc_have_winner", "orc_to_play", "orc_decide", "orc_expert_action"):
     getattr(LIB, name).argtypes = None
 
 UNSUPPORTED = set() if EXT else {"ua20", "b005"}
@@ -78,7 +78,7 @@ def describe_diff(a, b):
     return f"length {len(a)} vs {len(b)}"
 
 
-def play(seed, d0, d1, steps, policy_seed, verbose=False):
+def play(seed, d0, d1, steps, policy_seed, verbose=False, expert=False):
     g = H.make_game(seed, d0, d1)
     mir = Mirror()
     f = mir.reset(seed, d0, d1)
@@ -93,7 +93,22 @@ def play(seed, d0, d1, steps, policy_seed, verbose=False):
         lb = mir.legal()
         if la != lb:
             return f"seed {seed} step {t}: legal differs ref={la} ours={lb}", n
-        a = int(la[pol.randint(0, len(la))])
+        if expert:
+            # both sides are the reference's scripted bot (games/stormbound.py:563-637); it draws from the game stream
+            try:
+                a = int(g.expert_action())
+            except Exception as e:  # noqa: BLE001
+                fo = ctypes.c_int()
+                LIB.orc_expert_action(mir.h, 0, ctypes.byref(fo))
+                if fo.value == 0:
+                    return f"seed {seed} step {t}: reference expert raised {e!r}, ours did not", n
+                return None, n
+            fo = ctypes.c_int()
+            b = LIB.orc_expert_action(mir.h, 0, ctypes.byref(fo))
+            if fo.value != 0 or a != b:
+                return f"seed {seed} step {t}: expert action ref={a} ours={b} fault={fo.value}", n
+        else:
+            a = int(la[pol.randint(0, len(la))])
         ref_exc = None
         try:
             obs, reward, done = g.step(a)
@@ -133,6 +148,7 @@ def main():
     ap.add_argument("--games", type=int, default=20)
     ap.add_argument("--steps", type=int, default=400)
     ap.add_argument("--seed0", type=int, default=0)
+    ap.add_argument("--expert", action="store_true", help="drive both sides with Stormbound.expert_action")
     ap.add_argument("--must", default="", help="comma list of card ids forced into both random decks (with --pool)")
     args = ap.parse_args()
     total, bad = 0, 0
@@ -150,7 +166,7 @@ def main():
         else:
             d0 = H.DECKS[args.deck]
             d1 = H.DECKS[args.deck2 or args.deck]
-        err, n = play(seed, d0, d1, args.steps, policy_seed=seed + 1000)
+        err, n = play(seed, d0, d1, args.steps, policy_seed=seed + 1000, expert=args.expert)
         total += n
         if err:
             bad += 1

@@ -11,6 +11,7 @@ by running it here and committing inputs + expected outputs (data only, no refer
                                observation hash, reward, done (+ features for N12M)
   trace_pool.npz           G3/G5 random 12-card decks from the 107 cards of the standard record (card coverage)
   trace_pool_ext.npz       G3/G5 the same over all 109 observable cards (ua20, b005: extended record)
+  trace_expert.npz         (f1) both sides driven by Stormbound.expert_action (the bot's choices are the actions)
   trace_heuristic_N12M.npz G3  corrected heuristic self-play (SURVEY §8c contract), W0 both sides:
                                chosen action, best score, score hash, state hash per decision
   initial_states.npz       G2  canonical records right after construction
@@ -104,7 +105,8 @@ def gen_score():
 
 # ---------------------------------------------------------------------------------------------
 def random_trace(args):
-    seed, d0, d1, steps, want_feat = args
+    seed, d0, d1, steps, want_feat = args[:5]
+    expert = len(args) > 5 and args[5]
     from evo.features import StateFeatures
     g = H.make_game(seed, d0, d1)
     pol = np.random.RandomState(seed + 1000)
@@ -112,7 +114,14 @@ def random_trace(args):
     init_hash = H.fnv1a64(H.canon(g))
     for _ in range(steps):
         la = g.legal_actions()
-        a = int(la[pol.randint(0, len(la))])
+        try:
+            # expert traces: both sides are Stormbound.expert_action (games/stormbound.py:563-637)
+            a = int(g.expert_action()) if expert else int(la[pol.randint(0, len(la))])
+        except Exception:  # noqa: BLE001  random.choice([]) inside the bot: the trace ends here
+            rec["legal"].append(H.legal_mask(la))
+            rec["action"].append(255)
+            rec["fault"] = 1
+            break
         try:
             with contextlib.redirect_stdout(io.StringIO()):
                 obs, reward, done = g.step(a)
@@ -169,6 +178,25 @@ def gen_random(deck, deck2, n_games, steps, jobs, want_feat=False, seed0=0):
     with ProcessPoolExecutor(jobs) as ex:
         results = list(ex.map(random_trace, tasks))
     pack_traces(f"trace_random_{deck}.npz", jobs, results, [idx(d0)] * n_games, [idx(d1)] * n_games)
+
+
+def gen_expert(n_games, steps, jobs):
+    pool = [c for c in H.CARD_IDS if c not in UNSUPPORTED and c not in FAULT_CARDS]
+    tasks, decks0, decks1 = [], [], []
+    for k in range(n_games):
+        seed = 60000 + k
+        if k < n_games // 2:
+            d0, d1 = H.DECKS["IRONCLAD"], H.DECKS["SWARM"]
+        else:
+            rs = np.random.RandomState(seed ^ 0x9E3779B9)
+            d0 = list(rs.choice(pool, 12, replace=False))
+            d1 = list(rs.choice(pool, 12, replace=False))
+        tasks.append((seed, d0, d1, steps, False, True))
+        decks0.append(idx(d0))
+        decks1.append(idx(d1))
+    with ProcessPoolExecutor(jobs) as ex:
+        results = list(ex.map(random_trace, tasks))
+    pack_traces("trace_expert.npz", jobs, results, decks0, decks1)
 
 
 def gen_pool(n_games, steps, jobs, ext=False):
@@ -293,6 +321,7 @@ def main():
         "pool": lambda: gen_pool(160, 300, args.jobs),
         "pool_ext": lambda: gen_pool(120, 300, args.jobs, ext=True),   # all 109 observable cards (ua20, b005 included)
         "random_S12": lambda: gen_random("S12", None, 48, 300, args.jobs),
+        "expert": lambda: gen_expert(48, 300, args.jobs),
         "heuristic": lambda: gen_heuristic(12, 200, args.jobs),
     }
     for name, fn in todo.items():

@@ -33,6 +33,7 @@ def lib(extended=False):
         L.orc_reset.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
         L.orc_legal.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
         L.orc_step.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]
+        L.orc_expert_action.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_int)]
         L.orc_observe.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
         L.orc_features.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
         L.orc_canon.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
@@ -102,6 +103,11 @@ class Oracle:
         r, d = ctypes.c_int(), ctypes.c_int()
         f = self.L.orc_step(self.h, i, int(action), ctypes.byref(r), ctypes.byref(d))
         return f, r.value, d.value
+
+    def expert_action(self, i):
+        f = ctypes.c_int()
+        a = self.L.orc_expert_action(self.h, i, ctypes.byref(f))
+        return a, f.value
 
     def observe(self, i):
         out = np.zeros(540, dtype=np.int32)

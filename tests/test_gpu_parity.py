@@ -88,6 +88,34 @@ def test_random_policy_traces_vs_reference(engines, gold, name):
                 assert np.array_equal(feat[k].view(np.uint64), g["feat"][off[k + 1] - 1].view(np.uint64)), k
 
 
+def test_expert_bot_vs_reference(engines, gold):
+    """monsoon_expert_action + monsoon_step against the reference's scripted bot playing both sides."""
+    g = gold("trace_expert.npz")
+    n = len(g["seeds"])
+    eng = engines(256)
+    eng.reset(g["seeds"], np.stack([g["deck0"], g["deck1"]], axis=1))
+    off = g["offsets"]
+    lens = off[1:] - off[:-1]
+    for t in range(int(lens.max())):
+        live = np.nonzero(lens > t)[0]
+        action, fault = eng.expert_action()   # advances every game's stream; finished traces are simply ignored
+        acts = np.full(n, 255, dtype=np.uint8)
+        for k in live:
+            i = off[k] + t
+            if g["action"][i] == 255:
+                assert fault[k] != 0, (k, t)
+                continue
+            assert fault[k] == 0 and action[k] == g["action"][i], (k, t, action[k], g["action"][i])
+            acts[k] = action[k]
+        _, _, sf = eng.step(acts)
+        hashes = eng.state_hash()
+        for k in live:
+            i = off[k] + t
+            if acts[k] == 255 or (g["fault"][k] and t == lens[k] - 1):
+                continue
+            assert sf[k] == 0 and hashes[k] == g["hash"][i], (k, t)
+
+
 def test_heuristic_selfplay_vs_reference(engines, gold):
     """monsoon_decide against the reference's HeuristicAgent self-play (corrected loop): action,
     complete score vector, best score and committed state at each of 2 400 decisions."""

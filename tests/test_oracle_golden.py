@@ -87,6 +87,32 @@ def test_random_policy_traces(oracle_mod, gold, name, feat):
     assert steps == len(g["action"])
 
 
+def test_expert_bot_traces(oracle_mod, gold):
+    """Stormbound.expert_action (games/stormbound.py:563-637) on both sides: the bot's choice (drawn from the
+    game stream) and the resulting state at every step."""
+    g = gold("trace_expert.npz")
+    orc = oracle_mod.Oracle(1)
+    n_actions = 0
+    for k in range(len(g["seeds"])):
+        lo, hi = int(g["offsets"][k]), int(g["offsets"][k + 1])
+        assert orc.reset(0, int(g["seeds"][k]), g["deck0"][k], g["deck1"][k]) == 0
+        for t in range(lo, hi):
+            assert np.array_equal(orc.legal_mask(0), g["legal"][t]), (k, t)
+            a, f = orc.expert_action(0)
+            if g["action"][t] == 255:   # the reference's bot raised (random.choice([]))
+                assert f != 0, (k, t)
+                break
+            assert f == 0 and a == g["action"][t], (k, t, a, g["action"][t])
+            fs, r, d = orc.step(0, a)
+            if g["fault"][k] and t == hi - 1:
+                assert fs != 0 or orc.observe(0) is None
+                break
+            assert fs == 0 and orc.canon_hash(0) == int(g["hash"][t]), (k, t)
+            assert (r, d) == (int(g["reward"][t]), int(g["done"][t]))
+            n_actions += 1
+    assert n_actions > 2500
+
+
 def test_extended_record_pool_traces(oracle_mod, gold):
     """All 109 observable cards (ua20, b005 included) on the extended build.  The one behaviour the
     record cannot express -- restoring a NESTED b005 memory, whose entities live on a deep-copied
