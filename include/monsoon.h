@@ -85,6 +85,11 @@ int monsoon_expert_action(monsoon_t* h, uint8_t* out_action, uint8_t* fault);
  * raises[n] = 1 where the reference would raise (int(card) on up01/up02/up03, card.py:46). */
 int monsoon_observe(monsoon_t* h, int32_t* out, uint8_t* raises);
 
+/* The same into caller-owned DEVICE memory (a torch-ROCm tensor view (B,27,5,4) int32
+ * without a host round trip): out_dev = n*540 int32, raises_dev = n bytes or NULL.  Returns after the
+ * handle's stream has finished writing. */
+int monsoon_observe_dev(monsoon_t* h, void* out_dev, void* raises_dev);
+
 /* StateFeatures.get_feature_vector (evo/features.py:12-342): out[n][10] float64. */
 int monsoon_features(monsoon_t* h, double* out);
 

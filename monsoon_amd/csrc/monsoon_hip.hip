@@ -811,6 +811,20 @@ int monsoon_observe(monsoon_t* h, int32_t* out, uint8_t* raises) {
   return MONSOON_OK;
 }
 
+// Device-pointer variant: writes (n,27,5,4) int32 straight into caller-owned DEVICE memory (e.g. a torch-ROCm
+// tensor's data_ptr) -- no host round trip.  raises_dev (n bytes, device) may be NULL.
+int monsoon_observe_dev(monsoon_t* h, void* out_dev, void* raises_dev) {
+  int rc = check_ready(h);
+  if (rc) return rc;
+  if (!out_dev) return MONSOON_ERR_ARG;
+  int n = h->n;
+  uint8_t* r = raises_dev ? (uint8_t*)raises_dev : h->d_bytes;
+  hipLaunchKernelGGL(k_observe, dim3((n + API_LANES - 1) / API_LANES), dim3(64), API_LDS_BYTES, h->stream, h->b, n, (int32_t*)out_dev, r);
+  HIP_TRY(h, hipGetLastError());
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  return MONSOON_OK;
+}
+
 int monsoon_features(monsoon_t* h, double* out) {
   int rc = check_ready(h);
   if (rc) return rc;

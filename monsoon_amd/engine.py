@@ -26,6 +26,7 @@ class BatchEngine:
             self.h = None
             raise MonsoonError(f"monsoon_create failed (status {rc}): {msg.decode() if msg else ''}")
         self.max_games = max_games
+        self.device = device
         self.n = 0
 
     def close(self):
@@ -86,6 +87,18 @@ class BatchEngine:
         out = np.zeros((self.n, 27, 5, 4), dtype=np.int32)
         raises = np.zeros(self.n, dtype=np.uint8)
         self._ck(self.lib.monsoon_observe(self.h, _ptr(out), _ptr(raises)), "monsoon_observe")
+        return out, raises
+
+    def observe_torch(self):
+        """(n,27,5,4) int32 observation as a torch tensor ON THE GPU (no host copy), plus the raises mask.
+        torch is used for device memory only."""
+        import torch
+        dev = torch.device("cuda", self.device)
+        out = torch.empty((self.n, 27, 5, 4), dtype=torch.int32, device=dev)
+        raises = torch.empty((self.n,), dtype=torch.uint8, device=dev)
+        torch.cuda.synchronize(dev)
+        self._ck(self.lib.monsoon_observe_dev(self.h, ctypes.c_void_p(out.data_ptr()), ctypes.c_void_p(raises.data_ptr())),
+                 "monsoon_observe_dev")
         return out, raises
 
     def features(self):

@@ -209,6 +209,20 @@ def test_full_size_65536_games_bit_exact_and_deterministic(engines):
     assert eng.stats()["capacity_faults"] == 0
 
 
+def test_observation_tensor_view_on_device(engines):
+    """the batched observation lands in a torch-ROCm tensor without a host round trip."""
+    import torch
+    eng = engines(256)
+    deck = deck_indices("N12M")
+    eng.reset(np.arange(200, dtype=np.uint32), np.stack([deck, deck]))
+    for _ in range(5):
+        eng.decide(W0)
+    host, raises = eng.observe()
+    dev, draises = eng.observe_torch()
+    assert dev.is_cuda and dev.shape == (200, 27, 5, 4) and dev.dtype == torch.int32
+    assert np.array_equal(dev.cpu().numpy(), host) and np.array_equal(draises.cpu().numpy(), raises)
+
+
 def test_game_view_and_error_behaviour(engines):
     from monsoon_amd import MonsoonError
     from monsoon_amd.engine import BatchEngine
