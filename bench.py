@@ -71,6 +71,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--games", type=int, default=65536)
     ap.add_argument("--lanes", type=int, default=0)
+    ap.add_argument("--stack", type=int, default=0, help="per-lane scratch stack bytes (0 = library default)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=8192)
     ap.add_argument("--cpu-threads", type=int, default=16)
@@ -88,7 +89,7 @@ def main():
         dist.init_process_group("nccl")   # RCCL on ROCm
 
     n = args.games
-    eng = BatchEngine(n, device=local_rank, lanes_per_game=args.lanes)
+    eng = BatchEngine(n, device=local_rank, lanes_per_game=args.lanes, stack_bytes=args.stack)
     deck = deck_indices("N12M")
     seeds = (np.arange(n, dtype=np.uint64) + np.uint64(rank) * np.uint64(n)).astype(np.uint32)
     eng.reset(seeds, np.stack([deck, deck]))

@@ -65,6 +65,7 @@ SIGNATURES = {
     "monsoon_decide_round_dev": (ctypes.c_int, [ctypes.c_void_p]),
     "monsoon_sync": (ctypes.c_int, [ctypes.c_void_p]),
     "monsoon_get_stats": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(Stats)]),
+    "monsoon_debug_counters": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p]),
     "monsoon_reset_stats": (ctypes.c_int, [ctypes.c_void_p]),
     "monsoon_kernel_time": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int64)]),
     "monsoon_stream": (ctypes.c_void_p, [ctypes.c_void_p]),
@@ -76,11 +77,15 @@ def load(extended=False):
     if extended in _libs:
         return _libs[extended]
     path = LIB_PATH_EXT if extended else LIB_PATH
+    if not extended and os.environ.get("MONSOON_LIB"):
+        path = os.environ["MONSOON_LIB"]   # development knob: A/B another build of the same ABI (scripts/ab_bench.sh)
     if not os.path.exists(path):
         raise MonsoonError(f"{path} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                            "or `make -C monsoon_amd/csrc all` (there is no CPU fallback)")
     lib = ctypes.CDLL(path)
     for name, (res, args) in SIGNATURES.items():
+        if path not in (LIB_PATH, LIB_PATH_EXT) and not hasattr(lib, name):
+            continue              # an older build loaded through MONSOON_LIB may lack newer diagnostics entry points
         fn = getattr(lib, name)   # AttributeError if the ABI and this binding drift apart
         fn.restype = res
         fn.argtypes = args

@@ -26,6 +26,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
 #include <string>
 #include <vector>
 
@@ -64,9 +65,47 @@ struct DevBuffers {
   unsigned long long* stats;  // [8]: lookahead, decisions, finished, faults, capacity_faults
   double* scores;      // [cap][156] or null
   double* best;        // [cap]
+  unsigned long long* prof;   // [cap][72] phase cycles, scope cycles, scope calls, profiling build only (else null)
 };
 
-enum { ST_LOOKAHEAD = 0, ST_DECISIONS = 1, ST_FINISHED = 2, ST_FAULTS = 3, ST_CAPFAULTS = 4 };
+enum { ST_LOOKAHEAD = 0, ST_DECISIONS = 1, ST_FINISHED = 2, ST_FAULTS = 3, ST_CAPFAULTS = 4, ST_PROF = 8, ST_WORDS = 32, PROF_WORDS = 74 };
+// Phase timing of k_decide (profiling build only, -DMSB_PROF=1 -> libmonsoon_hip_prof.so; never the product):
+// wave cycles per phase accumulated into stats[ST_PROF + phase].
+#if defined(MSB_PROF) && MSB_PROF
+#define PROF_DECL()                                                                                   \
+  unsigned long long prof_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};                                          \
+  const unsigned long long prof_wall0 = wall_clock64();                                               \
+  if (lane < 32) {                                                                                    \
+    *(MSB_AS_LDS unsigned long long*)(uintptr_t)(MSB_PROF_LDS + 8 * lane) = 0ull;                     \
+    *(MSB_AS_LDS unsigned*)(uintptr_t)(MSB_PROF_LDS + 256 + 4 * lane) = 0u;                           \
+  }                                                                                                   \
+  __syncthreads();                                                                                    \
+  unsigned long long prof_t = __builtin_readcyclecounter()
+#define PROF_MARK(ph)                                         \
+  do {                                                        \
+    unsigned long long now_ = __builtin_readcyclecounter();   \
+    prof_acc[ph] += now_ - prof_t;                            \
+    prof_t = now_;                                            \
+  } while (0)
+#define PROF_FLUSH()                                                        \
+  do {                                                                      \
+    __syncthreads();                                                        \
+    if (lane == 0)                                                          \
+      for (int i_ = 0; i_ < 8; i_++) b.prof[(size_t)g * PROF_WORDS + i_] += prof_acc[i_]; \
+    if (lane == 0) {                                                        \
+      b.prof[(size_t)g * PROF_WORDS + 72] = prof_wall0;                     \
+      b.prof[(size_t)g * PROF_WORDS + 73] = wall_clock64();                 \
+    }                                                                       \
+    if (lane < 32) {                                                        \
+      b.prof[(size_t)g * PROF_WORDS + 8 + lane] += *(MSB_AS_LDS unsigned long long*)(uintptr_t)(MSB_PROF_LDS + 8 * lane); \
+      b.prof[(size_t)g * PROF_WORDS + 40 + lane] += *(MSB_AS_LDS unsigned*)(uintptr_t)(MSB_PROF_LDS + 256 + 4 * lane);   \
+    }                                                                       \
+  } while (0)
+#else
+#define PROF_DECL() do {} while (0)
+#define PROF_MARK(ph) do {} while (0)
+#define PROF_FLUSH() do {} while (0)
+#endif
 
 // ------------------------------------------------------------------------------------------------
 // RNG block maintenance (wave-cooperative, in LDS)
@@ -151,7 +190,11 @@ constexpr int API_LANES = 64;
 #endif
 // LDS address 0 is avoided on purpose: an integer constant 0 cast to an LDS pointer is the null pointer,
 // which is not address 0 on this target; every region starts at LDS_ORIGIN.
+#if defined(MSB_PROF) && MSB_PROF
+constexpr int LDS_ORIGIN = 400;   // [16,400): function-scope counters of the profiling build (msb_base.h)
+#else
 constexpr int LDS_ORIGIN = 16;
+#endif
 constexpr int API_LDS_BYTES = LDS_ORIGIN + SG * API_LANES * 16;
 typedef LaneMem<API_LANES, LDS_ORIGIN> ApiMem;
 typedef Engine<ApiMem> ApiEngine;
@@ -364,6 +407,7 @@ __global__ void __launch_bounds__(64, WPE) k_decide(DevBuffers b, int n, int max
     }
     return;
   }
+  PROF_DECL();
   MSB_AS_LDS u32x4* par = (MSB_AS_LDS u32x4*)(uintptr_t)L::PAR;
   MSB_AS_LDS u32x4* priv = (MSB_AS_LDS u32x4*)(uintptr_t)L::PRIV;
   MSB_AS_LDS u32x4* bestcol = (MSB_AS_LDS u32x4*)(uintptr_t)L::BEST;
@@ -390,9 +434,11 @@ __global__ void __launch_bounds__(64, WPE) k_decide(DevBuffers b, int n, int max
     return;
   }
 
+  PROF_MARK(0);   // stage
   const msb_u64x4 lm = pe.legal_mask_v();
   const uint64_t mask[3] = {lm[0], lm[1], lm[2]};
   const int n_legal = __popcll(mask[0]) + __popcll(mask[1]) + __popcll(mask[2]);
+  PROF_MARK(1);   // legal mask
   const bool before_raises = pe.observation_raises();
   // weights and "before" features are parked in LDS: 40 fewer live VGPRs across the recursive step calls
   MSB_AS_LDS double* wf = (MSB_AS_LDS double*)(uintptr_t)L::WF;
@@ -405,6 +451,7 @@ __global__ void __launch_bounds__(64, WPE) k_decide(DevBuffers b, int n, int max
       for (int i = 0; i < 10; i++) wf[10 + i] = fb[i];
   }
   __syncthreads();
+  PROF_MARK(2);   // before-features
 
   CandEngine ce;
   // Running best over the passes (uniform across the wave).  When the legal set needs more than
@@ -422,12 +469,26 @@ __global__ void __launch_bounds__(64, WPE) k_decide(DevBuffers b, int n, int max
     int a = NONE_A;
     uint32_t my_pos = 0;
     int my_fault = 0;
+    int f = 0;
+    bool raises = false;
+    // copy.deepcopy (stream window included) for the whole pass, by all 64 lanes: granule idx of the interleaved
+    // candidate image is parent granule idx / U for column idx % U
+    {
+      const int n_act = n_legal - base < U ? n_legal - base : U;
+      __syncthreads();
+      for (int idx = lane; idx < SG * U; idx += 64)
+        if ((idx & (U - 1)) < n_act) priv[idx] = par[idx / U];
+      __syncthreads();
+    }
+    if (lane < U && k < n_legal) a = nth_set_bit(mask, k);
+    PROF_MARK(3);   // clone
     if (lane < U && k < n_legal) {
-      a = nth_set_bit(mask, k);
-      for (int c = 0; c < SG; c++) priv[c * U + lane] = par[c];   // copy.deepcopy (stream window included)
       ce.step(a);
-      int f = ce.fault();
-      bool raises = f == 0 && ce.observation_raises();
+      f = ce.fault();
+      raises = f == 0 && ce.observation_raises();
+    }
+    PROF_MARK(4);   // step
+    if (lane < U && k < n_legal) {
       if (f == 0 && !before_raises && !raises) {
         double fa[10], wv[10], fbv[10];
         ce.features(fa);
@@ -441,6 +502,7 @@ __global__ void __launch_bounds__(64, WPE) k_decide(DevBuffers b, int n, int max
       my_pos = ce.rng_pos();
       my_fault = f ? f : (raises ? FAULT_INT_CARD : 0);
     }
+    PROF_MARK(5);   // after-features + score
     // first maximum over the ascending legal list == (max score, then min action id)
     double cs = s;
     int ca = a;
@@ -466,6 +528,7 @@ __global__ void __launch_bounds__(64, WPE) k_decide(DevBuffers b, int n, int max
         __syncthreads();
       }
     }
+    PROF_MARK(6);   // argmax + park
   }
   const int A = run_a;
   const double rs = run_s;
@@ -501,6 +564,8 @@ __global__ void __launch_bounds__(64, WPE) k_decide(DevBuffers b, int n, int max
     b.meta[g] = meta;
     if (b.best) b.best[g] = rs;
   }
+  PROF_MARK(7);   // commit + refill
+  PROF_FLUSH();
 }
 
 __global__ void k_clear_scores(double* scores, size_t n) {
@@ -622,7 +687,7 @@ const char* monsoon_last_error(monsoon_t* h) { return h ? h->err.c_str() : g_cre
 void monsoon_destroy(monsoon_t* h) {
   if (!h) return;
   hipSetDevice(h->device);
-  void* ptrs[] = {h->b.state, h->b.rng_out, h->b.rng_mt, h->b.meta, h->b.weights, h->b.stats, h->b.scores, h->b.best,
+  void* ptrs[] = {h->b.state, h->b.rng_out, h->b.rng_mt, h->b.meta, h->b.weights, h->b.stats, h->b.scores, h->b.best, h->b.prof,
                   h->d_bytes, h->d_decks, h->d_factions, h->d_seeds, h->d_masks, h->d_i32, h->d_f64, h->d_p1, h->d_p2, h->d_int};
   for (void* p : ptrs)
     if (p) hipFree(p);
@@ -680,9 +745,13 @@ int monsoon_create(const monsoon_config* cfg, monsoon_t** out) {
   HIP_TRY(h, hipMalloc(&h->b.rng_mt, cap * MT_N * 4));
   HIP_TRY(h, hipMalloc(&h->b.meta, cap * sizeof(GameMeta)));
   HIP_TRY(h, hipMemset(h->b.meta, 0, cap * sizeof(GameMeta)));
-  HIP_TRY(h, hipMalloc(&h->b.stats, 8 * sizeof(unsigned long long)));
-  HIP_TRY(h, hipMemset(h->b.stats, 0, 8 * sizeof(unsigned long long)));
+  HIP_TRY(h, hipMalloc(&h->b.stats, ST_WORDS * sizeof(unsigned long long)));
+  HIP_TRY(h, hipMemset(h->b.stats, 0, ST_WORDS * sizeof(unsigned long long)));
   HIP_TRY(h, hipMalloc(&h->b.best, cap * sizeof(double)));
+#if defined(MSB_PROF) && MSB_PROF
+  HIP_TRY(h, hipMalloc(&h->b.prof, cap * PROF_WORDS * sizeof(unsigned long long)));
+  HIP_TRY(h, hipMemset(h->b.prof, 0, cap * PROF_WORDS * sizeof(unsigned long long)));
+#endif
   HIP_TRY(h, hipMalloc(&h->d_decks, cap * 24));
   HIP_TRY(h, hipMalloc(&h->d_factions, cap * 2));
   HIP_TRY(h, hipMalloc(&h->d_seeds, cap * 4));
@@ -929,7 +998,8 @@ static int launch_decide(monsoon_t* h, int n, int max_turns, int write_scores, b
     HIP_TRY(h, hipEventCreate(&e1));
     HIP_TRY(h, hipEventRecord(e0, h->stream));
   }
-#define MSB_LAUNCH(U, W) hipLaunchKernelGGL((k_decide<U, W>), dim3(n), dim3(64), DecideLds<U>::TOTAL, h->stream, h->b, n, max_turns, write_scores)
+  static const int lds_pad = getenv("MONSOON_LDS_PAD") ? atoi(getenv("MONSOON_LDS_PAD")) : 0;   // occupancy experiments only
+#define MSB_LAUNCH(U, W) hipLaunchKernelGGL((k_decide<U, W>), dim3(n), dim3(64), DecideLds<U>::TOTAL + lds_pad, h->stream, h->b, n, max_turns, write_scores)
   int variant = h->cfg.lanes_per_game * 10 + h->wpe;
   switch (variant) {
     case 81: MSB_LAUNCH(8, 1); break;
@@ -1112,12 +1182,62 @@ int monsoon_get_stats(monsoon_t* h, monsoon_stats* out) {
   return MONSOON_OK;
 }
 
+// Raw counter words; out = 128 u64 (profiling builds: k_decide phase cycles at 8.., function scopes at 32.. / 64..).
+int monsoon_debug_counters(monsoon_t* h, unsigned long long* out) {
+  if (!h || !out) return MONSOON_ERR_ARG;
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  memset(out, 0, 128 * sizeof(unsigned long long));
+  HIP_TRY(h, hipMemcpy(out, h->b.stats, ST_WORDS * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+#if defined(MSB_PROF) && MSB_PROF
+  {
+    std::vector<unsigned long long> v((size_t)h->cfg.max_games * PROF_WORDS);
+    HIP_TRY(h, hipMemcpy(v.data(), h->b.prof, v.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < v.size(); i++) {
+      size_t k = i % PROF_WORDS;
+      if (k < 72) out[k < 8 ? ST_PROF + k : 32 + (k - 8)] += v[i];   // 32..63 scope cycles, 64..95 scope calls
+    }
+    // occupancy of the LAST launch from the per-wave wall-clock stamps (100 MHz): span, sum of wave times,
+    // time at which the 4096th-from-last wave ended (start of the tail)
+    {
+      std::vector<unsigned long long> st, en;
+      unsigned long long newest = 0;
+      for (int g = 0; g < h->n; g++) newest = std::max(newest, v[(size_t)g * PROF_WORDS + 73]);
+      for (int g = 0; g < h->n; g++) {
+        unsigned long long a = v[(size_t)g * PROF_WORDS + 72], e = v[(size_t)g * PROF_WORDS + 73];
+        if (e > a && e + 1000000ull > newest) {   // stamps of the last launch only (within 10 ms of the newest)
+          st.push_back(a);
+          en.push_back(e);
+        }
+      }
+      if (!st.empty()) {
+        unsigned long long t0 = *std::min_element(st.begin(), st.end()), t1 = *std::max_element(en.begin(), en.end());
+        unsigned long long sum = 0, longest = 0;
+        for (size_t i = 0; i < st.size(); i++) {
+          sum += en[i] - st[i];
+          longest = std::max(longest, en[i] - st[i]);
+        }
+        std::sort(en.begin(), en.end());
+        std::sort(st.begin(), st.end());
+        out[96] = t1 - t0;
+        out[97] = sum;
+        out[98] = en.size() > 4096 ? en[en.size() - 4096] - t0 : 0;
+        out[99] = longest;
+        out[100] = st.size();
+        out[101] = st.back() - t0;   // when the last wave started
+      }
+    }
+  }
+#endif
+  return MONSOON_OK;
+}
+
 int monsoon_reset_stats(monsoon_t* h) {
   if (!h) return MONSOON_ERR_ARG;
   HIP_TRY(h, hipSetDevice(h->device));
   HIP_TRY(h, hipStreamSynchronize(h->stream));
   drain_timing(h);
-  HIP_TRY(h, hipMemset(h->b.stats, 0, 8 * sizeof(unsigned long long)));
+  HIP_TRY(h, hipMemset(h->b.stats, 0, ST_WORDS * sizeof(unsigned long long)));
+  if (h->b.prof) HIP_TRY(h, hipMemset(h->b.prof, 0, (size_t)h->cfg.max_games * PROF_WORDS * sizeof(unsigned long long)));
   h->kernel_ms = 0;
   h->kernel_launches = 0;
   return MONSOON_OK;

@@ -19,6 +19,38 @@
 #endif
 #define MSB_INL inline __attribute__((always_inline))
 
+// Function-level timing scopes of the profiling build (-DMSB_PROF=1, scripts/phase_profile.py only): the leader
+// lane of whatever sub-wave executes a function adds the elapsed wave cycles to an LDS counter.  Inclusive
+// times; nested/recursive scopes count twice.  Expands to nothing in the product and in the oracle.
+#define MSB_PROF_LDS 16          // u64 cycles[32] then u32 calls[32]; the records start at 400 in that build
+#if defined(MSB_PROF) && MSB_PROF && defined(__HIP_DEVICE_COMPILE__)
+struct ProfScope {
+  unsigned long long t0;
+  int id;
+  __device__ inline __attribute__((always_inline)) explicit ProfScope(int i) : t0(__builtin_readcyclecounter()), id(i) {}
+  __device__ inline __attribute__((always_inline)) ~ProfScope() {
+    unsigned long long dt = __builtin_readcyclecounter() - t0;
+    unsigned l = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    if ((unsigned)__builtin_amdgcn_readfirstlane((int)l) == l) {
+      typedef __attribute__((address_space(3))) unsigned long long* lds64;
+      typedef __attribute__((address_space(3))) unsigned* lds32;
+      __hip_atomic_fetch_add((lds64)(unsigned long)(MSB_PROF_LDS + 8 * id), dt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      __hip_atomic_fetch_add((lds32)(unsigned long)(MSB_PROF_LDS + 256 + 4 * id), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+  }
+};
+#define MSB_SCOPE(id) ProfScope msb_prof_scope_(id)
+#else
+#define MSB_SCOPE(id)
+#endif
+enum {
+  PS_STEP, PS_PLAYER_PLAY, PS_NEW_ENTITY, PS_RUN_ABILITY, PS_ABILITY_ENTITY, PS_ABILITY_SPELL, PS_GET_TARGETS, PS_SHAPE_TILES,
+  PS_SHAPE_TARGETS, PS_DEAL_DAMAGE, PS_DESTROY, PS_FRONT_LINE, PS_SET_PATH, PS_MOVE, PS_COMMAND, PS_FORCE_ATTACK, PS_DRAW,
+  PS_FLIP, PS_NEXT_TURN, PS_LEGAL, PS_SHUFFLE, PS_SORTED_HEAD, PS_SPAWN, PS_RESPAWN, PS_TELEPORT, PS_PUSH_PULL, PS_EMPTY_FRONT,
+  PS_BEGIN_STEP, PS_OBS_RAISES, PS_FEATURES, PS_COUNT
+};
+
+
 namespace msb {
 
 // ---- enums (reference enums.py) -------------------------------------------------------

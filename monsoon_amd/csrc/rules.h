@@ -405,20 +405,34 @@ struct Engine {
   // A free entity slot: not on the board and not referenced since the step began.
   MSB_HD MSB_INL int alloc_entity() {
     uint32_t used = m.ld32(H_USED);
-    for (int e = 0; e < NUM_ENT; e++) {
-      if (!(used & (1u << e))) {
-        m.st32(H_USED, used | (1u << e));
-        return e;
-      }
+    uint32_t free_mask = ~used & ((1u << NUM_ENT) - 1u);
+    if (free_mask == 0) {
+      set_fault(FAULT_CAPACITY);
+      return 0;
     }
-    set_fault(FAULT_CAPACITY);
-    return 0;
+    int e = __builtin_ctz(free_mask);   // lowest free slot (a search loop unrolls into 28 nested exec masks)
+    m.st32(H_USED, used | (1u << e));
+    return e;
   }
   // Called at the start of every step: everything not on the board is garbage in the reference
   // (no live Python reference survives a step).
   // the 20 board bytes as five 32-bit rows (row y = tiles 4y..4y+3, x in byte x): one LDS read per row
   MSB_HD MSB_INL uint32_t board_row(int y) const { return m.ld32(OFF_BOARD + 4 * y); }
+  // one bit per byte of a board row that is (occupied ? 1 : 0), bit x for tile x
+  MSB_HD MSB_INL static uint32_t row_occ4(uint32_t row) {
+    uint32_t t = ~row;                                                   // byte == 0 <=> SLOT_NONE (0xFF)
+    uint32_t nz = (((t & 0x7f7f7f7fu) + 0x7f7f7f7fu) | t) & 0x80808080u;  // bit 7 of every non-zero byte
+    return (((nz >> 7) * 0x00204081u) >> 21) & 0xFu;                     // gather bits 0,8,16,24 -> 0..3
+  }
+  // occupied / empty tiles as 20-bit masks (bit y*4+x): five LDS reads, no per-tile loop
+  MSB_HD MSB_INL uint32_t occ_mask() const {
+    uint32_t o = 0;
+    for (int y = 0; y < 5; y++) o |= row_occ4(board_row(y)) << (4 * y);
+    return o;
+  }
+  MSB_HD MSB_INL uint32_t empty_mask() const { return ~occ_mask() & 0xFFFFFu; }
   MSB_HD MSB_INL void begin_step() {
+    MSB_SCOPE(PS_BEGIN_STEP);
     uint32_t used = 0;
     for (int y = 0; y < 5; y++) {
       uint32_t row = board_row(y);
@@ -452,6 +466,7 @@ struct Engine {
     m.st8(H_DEPTH, 0);
   }
   MSB_HD MSB_NOINLINE int new_entity(int card, int owner, int strength, int movement, bool ff) {
+    MSB_SCOPE(PS_NEW_ENTITY);
     int e = alloc_entity();
     if (fault()) return e;
     // card | flags<<8 | pos<<16 | mov<<24 ; st0..st3 = 0 ; st4 = 0, move_id = 0, strength<<16 ; dmg = 0, path_n = 0
@@ -550,33 +565,29 @@ struct Engine {
   // Board.calculate_front_line, board.py:78-92.  `player` is an order; the reference compares
   // Player objects by order (player.py:39-40).
   MSB_HD MSB_NOINLINE void calculate_front_line(int player) {
-    // any(board[y][x] is not None and board[y][x].player == player for x in range(4)) per row
-    auto row_has = [&](int y) {
-      uint32_t row = board_row(y);
-      bool any = false;
-      for (int x = 0; x < 4; x++) {
-        uint32_t s = (row >> (8 * x)) & 0xff;
-        if (s != (uint32_t)SLOT_NONE && e_owner((int)s) == player) any = true;
+    MSB_SCOPE(PS_FRONT_LINE);
+    // any(board[y][x] is not None and board[y][x].player == player for x in range(4)) per row: the first
+    // (local: lowest y, remote: highest y) row holding one of the player's entities; only occupied tiles are read
+    const uint32_t r0 = board_row(0), r1 = board_row(1), r2 = board_row(2), r3 = board_row(3), r4 = board_row(4);
+    uint32_t occ = row_occ4(r0) | (row_occ4(r1) << 4) | (row_occ4(r2) << 8) | (row_occ4(r3) << 12) | (row_occ4(r4) << 16);
+    const unsigned long long b01 = (unsigned long long)r0 | ((unsigned long long)r1 << 32);
+    const unsigned long long b23 = (unsigned long long)r2 | ((unsigned long long)r3 << 32);
+    const bool is_local = player == local();
+    int found = -1;
+    while (occ) {
+      const int t = is_local ? __builtin_ctz(occ) : 31 - __builtin_clz(occ);
+      occ &= ~(1u << t);
+      const unsigned long long bw = t < 8 ? b01 : (t < 16 ? b23 : (unsigned long long)r4);
+      const int s = (int)((bw >> (8 * (t & 7))) & 0xff);
+      if (e_owner(s) == player) {
+        found = t >> 2;
+        break;
       }
-      return any;
-    };
-    if (player == local()) {
-      int fl = 4;
-      for (int y = 0; y < 5; y++)
-        if (row_has(y)) {
-          fl = y > 1 ? y : 1;
-          break;
-        }
-      set_pl_front(local(), fl);
-    } else {
-      int fl = 0;
-      for (int y = 4; y >= 0; y--)
-        if (row_has(y)) {
-          fl = y < 3 ? y : 3;
-          break;
-        }
-      set_pl_front(remote(), fl);
     }
+    if (is_local)
+      set_pl_front(local(), found < 0 ? 4 : (found > 1 ? found : 1));
+    else
+      set_pl_front(remote(), found < 0 ? 0 : (found < 3 ? found : 3));
   }
   // board.calculate_front_line(board.current_player.opponent), unit.py:231 / structure.py:69.
   // Player.opponent (player.py:42-44) is board.remote for the FIRST player, board.local for the
@@ -586,17 +597,25 @@ struct Engine {
 
   // Board.get_targets, board.py:147-204
   MSB_HD MSB_NOINLINE PList get_targets(int pov, Tgt t, int exclude_pk) {
+    MSB_SCOPE(PS_GET_TARGETS);
     PList out;
     out.clear();
     const bool asc = (pov == local());
     const int kind = tg_kind(t), side = tg_side(t), limit = tg_limit(t);
     const int types = tg_types(t), xtypes = tg_xtypes(t), status = tg_status(t), xstatus = tg_xstatus(t);
-    uint32_t row = 0;
-    for (int i = 0; i < 20; i++) {
-      int tile = asc ? i : 19 - i;
-      if ((i & 3) == 0) row = board_row(tile >> 2);   // four tiles per LDS read
-      int e = (int)((row >> (8 * (tile & 3))) & 0xff);
-      if (e == SLOT_NONE) continue;
+    const bool want_types = (types | xtypes | (tg_non_hero(t) ? 1 : 0)) != 0;
+    // Pass 1: visit only the occupied tiles and collect the matching ones as a tile bit mask (the board is
+    // read as five 32-bit rows; one 16-byte LDS read per entity).  Pass 2 emits them in iteration order.
+    const uint32_t r0 = board_row(0), r1 = board_row(1), r2 = board_row(2), r3 = board_row(3), r4 = board_row(4);
+    uint32_t occ = row_occ4(r0) | (row_occ4(r1) << 4) | (row_occ4(r2) << 8) | (row_occ4(r3) << 12) | (row_occ4(r4) << 16);
+    const unsigned long long b01 = (unsigned long long)r0 | ((unsigned long long)r1 << 32);
+    const unsigned long long b23 = (unsigned long long)r2 | ((unsigned long long)r3 << 32);
+    uint32_t hit = 0;
+    while (occ) {
+      const int tile = __builtin_ctz(occ);
+      occ &= occ - 1;
+      const unsigned long long bw = tile < 8 ? b01 : (tile < 16 ? b23 : (unsigned long long)r4);
+      const int e = (int)((bw >> (8 * (tile & 7))) & 0xff);
       const msb_u32x4 g = m.ld128(ent(e));   // the whole entity in one LDS read
       int str = (int)(int16_t)(g[2] >> 16);
       if (str <= 0) continue;
@@ -605,7 +624,7 @@ struct Engine {
       bool strength_ok = limit == LIMIT_NONE || str <= limit;
       bool ok;
       if (is_unit) {
-        int ty = (types | xtypes | (tg_non_hero(t) ? 1 : 0)) ? card_types(c) : 0;   // table lookup only for type filters
+        int ty = want_types ? card_types(c) : 0;   // table lookup only for type filters
         bool type_ok = types == 0 || (ty & types) != 0;
         bool xtype_ok = xtypes == 0 || (ty & xtypes) == 0;
         bool hero_ok = !tg_non_hero(t) || !(ty & (1 << UT_HERO));
@@ -621,10 +640,23 @@ struct Engine {
       } else {
         ok = strength_ok && (kind == TK_ANY || kind == TK_STRUCTURE);
       }
-      if (!ok) continue;
       int own = (int)((g[0] >> 8) & EF_OWNER);
       bool side_ok = side == TS_ANY || (side == TS_FRIENDLY && own == pov) || (side == TS_ENEMY && own != pov);
-      if (side_ok) out.push(tile_p(tile));
+      if (ok && side_ok) hit |= 1u << tile;
+    }
+    // ascending tiles for the local point of view, descending for the remote one (board.py:160-166)
+    {
+      unsigned long long w0 = 0, w1 = 0;
+      int n = 0;
+      while (hit) {
+        const int tile = asc ? __builtin_ctz(hit) : 31 - __builtin_clz(hit);
+        hit &= ~(1u << tile);
+        const unsigned long long v = (unsigned long long)((((tile >> 2) + 1) << 3) | ((tile & 3) + 1));   // p_pack(tile_p(tile))
+        if (n < 10) w0 |= v << (6 * n);
+        else w1 |= v << (6 * (n - 10));
+        n++;
+      }
+      out.w = msb_u64x4{w0, w1, 0ull, (unsigned long long)n};
     }
     if (tg_base(t)) {
       P friendly = asc ? P{-1, 5} : P{-1, -1};
@@ -658,6 +690,7 @@ struct Engine {
   }
   // get_front_tiles .. get_surrounding_tiles WITHOUT a target: fixed enumeration order.
   MSB_HD MSB_NOINLINE PList shape_tiles(int shape, P c, int pov) {
+    MSB_SCOPE(PS_SHAPE_TILES);
     PList out;
     out.clear();
     switch (shape) {
@@ -711,6 +744,7 @@ struct Engine {
   }
   // ... WITH a target: get_targets order filtered by membership; front/behind re-sorted by y.
   MSB_HD MSB_NOINLINE PList shape_targets(int shape, P c, int pov, Tgt t, int exclude_pk) {
+    MSB_SCOPE(PS_SHAPE_TARGETS);
     PList all = get_targets(pov, t, exclude_pk);
     PList out;
     out.clear();
@@ -743,6 +777,7 @@ struct Engine {
   MSB_HD MSB_INL int choice_index(int n) { return rng_randint(0, n); }
   MSB_HD MSB_INL P choice_point(PList l) { return l.at(choice_index(l.n())); }
   MSB_HD MSB_NOINLINE PList shuffle(PList l) {
+    MSB_SCOPE(PS_SHUFFLE);
     for (int i = l.n() - 1; i >= 1; i--) {
       int j = (int)rng_interval((uint32_t)i);
       int tmp = l.get(i);
@@ -756,6 +791,7 @@ struct Engine {
   // BEFORE sorting; the sort is stable and reverse keeps ties in order, so the first k of the sorted
   // list are the k best under (key, r) with earlier elements winning ties.  key_mode: 0 = y, 1 = strength.
   MSB_HD MSB_NOINLINE PList sorted_head(PList l, int key_mode, bool rev, int k) {
+    MSB_SCOPE(PS_SORTED_HEAD);
     int b0 = -1, b1 = -1, k0 = 0, k1 = 0;
     double r0 = 0.0, r1 = 0.0;
     int m = l.n();
@@ -805,6 +841,7 @@ struct Engine {
   // wrapped activate_ability.  subj >= 0: entity slot.  subj < 0: a spell, spell_card/spell_owner
   // passed in `spell`.  The trailing pop_trigger() is a tail call in the reference, hence a loop.
   MSB_HD MSB_NOINLINE void run_ability(int e, int spell, int pos_pk, bool src) {
+    MSB_SCOPE(PS_RUN_ABILITY);
     int d = m.ld8(H_DEPTH);
     if (d >= MAX_DEPTH) {
       set_fault(FAULT_DEPTH);
@@ -847,6 +884,7 @@ struct Engine {
 
   // Unit.deal_damage unit.py:205-219 / Structure.deal_damage structure.py:52-63
   MSB_HD MSB_NOINLINE int entity_deal_damage(int e, int amount, bool pending, bool src) {
+    MSB_SCOPE(PS_DEAL_DAMAGE);
     int s = e_str(e);
     if (s - amount < 0) amount = s;
     e_set_dmg(e, amount);
@@ -879,6 +917,7 @@ struct Engine {
   }
   // Unit.destroy unit.py:221-231 / Structure.destroy structure.py:65-69
   MSB_HD MSB_NOINLINE void destroy(int e, bool src) {
+    MSB_SCOPE(PS_DESTROY);
     if (e_is_unit(e)) {
       board_set(e_pos(e), -1);
       m.st8(ent(e) + EO_PATHN, 0);
@@ -931,6 +970,7 @@ struct Engine {
   // ------------------------------------------------------------------------------------------
   // Unit.set_path, unit.py:78-122
   MSB_HD MSB_NOINLINE void set_path(int e, bool on_play) {
+    MSB_SCOPE(PS_SET_PATH);
     P position = e_pos(e);
     int confused_cached = e_st(e, ST_CONFUSED);
     int owner = e_owner(e);
@@ -999,6 +1039,7 @@ struct Engine {
 
   // Unit.move, unit.py:124-203
   MSB_HD MSB_NOINLINE void move(int e) {
+    MSB_SCOPE(PS_MOVE);
     int d = m.ld8(H_DEPTH);
     if (d >= MAX_DEPTH) {
       set_fault(FAULT_DEPTH);
@@ -1102,6 +1143,7 @@ struct Engine {
   }
   // Unit.command, unit.py:282-289
   MSB_HD MSB_NOINLINE void command(int e) {
+    MSB_SCOPE(PS_COMMAND);
     if (!need_unit(e)) return;
     bool ff = e_ff(e);
     e_set_flag(e, EF_FF, true);
@@ -1118,6 +1160,7 @@ struct Engine {
   }
   // Unit.teleport, unit.py:373-382
   MSB_HD MSB_NOINLINE void teleport(int e, P dest) {
+    MSB_SCOPE(PS_TELEPORT);
     if (at(dest) == AT_NONE) {
       board_set(e_pos(e), -1);
       board_set(dest, e);
@@ -1128,6 +1171,7 @@ struct Engine {
   }
   // Unit.push (away from `from`) unit.py:318-339 and Unit.pull (towards) unit.py:295-316
   MSB_HD MSB_NOINLINE void push_pull(int e, P from, bool is_push) {
+    MSB_SCOPE(PS_PUSH_PULL);
     if (!need_unit(e)) return;
     P pos = e_pos(e);
     int dx = 0, dy = 0;
@@ -1154,6 +1198,7 @@ struct Engine {
   }
   // Unit.force_attack, unit.py:341-371
   MSB_HD MSB_NOINLINE void force_attack(int e, P dest) {
+    MSB_SCOPE(PS_FORCE_ATTACK);
     P pos = e_pos(e);
     if ((dest.x != pos.x && dest.y != pos.y) || at(dest) == AT_NONE) return;
     bool vertical = dest.x == pos.x;
@@ -1181,6 +1226,7 @@ struct Engine {
   }
   // Board.spawn_token_unit, board.py:298-311 (types always given by the cards)
   MSB_HD MSB_NOINLINE int spawn_token_unit(int owner, P position, int strength, int unit_type) {
+    MSB_SCOPE(PS_SPAWN);
     int e = new_entity(TOKEN_UNIT_BASE + unit_type, owner, strength, 1, false);
     if (fault()) return e;
     board_set(position, e);
@@ -1190,6 +1236,7 @@ struct Engine {
   // Unit.respawn unit.py:384-402 / Structure.respawn structure.py:77-89: a fresh object of the same
   // class with the given strength is written onto the tile (whatever was there is overwritten).
   MSB_HD MSB_NOINLINE void respawn(int e, P position, int strength) {
+    MSB_SCOPE(PS_RESPAWN);
     int c = e_card(e);
     int ne;
     if (c < NUM_CARDS)
@@ -1228,6 +1275,7 @@ struct Engine {
 
   // Player.draw, player.py:46-52: numpy choice(deck, size=1, p=w/sum(w))
   MSB_HD MSB_NOINLINE void draw(int o, int amount) {
+    MSB_SCOPE(PS_DRAW);
     for (int k = 0; k < amount; k++) {
       int n = pl_deck_n(o);
       if (n == 0) {
@@ -1297,6 +1345,7 @@ struct Engine {
   }
   // Player.play, player.py:68-77.  has_pos=false <=> position None
   MSB_HD MSB_NOINLINE void player_play(int o, int index, P position, bool has_pos) {
+    MSB_SCOPE(PS_PLAYER_PLAY);
     int card = hand_card(o, index), fl = hand_flags(o, index);
     int strength = inst_strength(card, fl, hand_x(o, index));   // target.copy() copies the instance's strength
     add_history(o, card);
@@ -1349,6 +1398,7 @@ struct Engine {
   // Board.flip, board.py:94-115.  H_TOPLAY has already been toggled by the caller, which swaps
   // local/remote; entity.player keeps the same PlayerOrder through the "ownership swap".
   MSB_HD MSB_NOINLINE void flip() {
+    MSB_SCOPE(PS_FLIP);
     set_pl_front(0, 4 - pl_front(0));
     set_pl_front(1, 4 - pl_front(1));
     // 180-degree rotation: new row y = byte-reversed old row 4-y
@@ -1365,6 +1415,7 @@ struct Engine {
   }
   // Board.to_next_turn, board.py:117-145
   MSB_HD MSB_NOINLINE void to_next_turn() {
+    MSB_SCOPE(PS_NEXT_TURN);
     m.st8(H_PHASE, PH_TURN_END);
     int ender = cp();
     fill_hand(ender);
@@ -1408,6 +1459,7 @@ struct Engine {
   // Stormbound.legal_actions + Action.to_int, games/stormbound.py:528-557, 258-290 -> 156-bit mask
   // (three 64-bit words in a register vector)
   MSB_HD MSB_NOINLINE msb_u64x4 legal_mask_v() {
+    MSB_SCOPE(PS_LEGAL);
     unsigned long long m0 = 0, m1 = 0, m2 = 0;
     int lo = local();
     int hn = pl_hand_n(lo), mana = pl_mana(lo), fl = pl_front(lo);
@@ -1419,18 +1471,28 @@ struct Engine {
     else if (a_ < 128) m1 |= 1ull << (a_ - 64);         \
     else if (a_ < 156) m2 |= 1ull << (a_ - 128);        \
   } while (0)
+    // empty tiles within the front line, as the 16 PLACE offsets (4-y)*4+x of one card (y = 4..max(fl,1));
+    // tiles of row 0 are not enumerated by Action.to_int and stay 155 (games/stormbound.py:262-271)
+    const uint32_t empty = empty_mask();
+    uint32_t place = 0;
+    for (int y = 4; y >= 1; y--)
+      if (y >= fl) place |= ((empty >> (4 * y)) & 0xFu) << ((4 - y) * 4);
+    const bool place_row0 = fl <= 0 && (empty & 0xFu) != 0;
     for (int c = 0; c < hn; c++) {
-      if (hand_cost(lo, c) > mana) continue;
-      int card = hand_card(lo, c);
+      const uint32_t inst = m.ld32(hand_ref(lo, c));   // {card, cost, flags, x}
+      if ((int)((inst >> 8) & 0xff) > mana) continue;
+      int card = (int)(inst & 0xff);
       const CardInfo& ci = g_cards[card];
       if (ci.kind != KIND_SPELL) {
-        for (int y = 4; y >= fl; y--)
-          for (int x = 0; x < 4; x++)
-            if (board_at(y * 4 + x) == SLOT_NONE) {
-              // to_int only enumerates y=4..1; anything else stays 155 (games/stormbound.py:262-271)
-              MSB_SETBIT((y >= 1) ? 16 * c + (4 - y) * 4 + x : 155);
-              any_play = true;
-            }
+        if (place) {
+          if (c < 4) m0 |= (unsigned long long)place << (16 * c);
+          else m1 |= (unsigned long long)place << (16 * c - 64);
+          any_play = true;
+        }
+        if (place_row0) {
+          MSB_SETBIT(155);
+          any_play = true;
+        }
       } else if (!ci.tgt.has) {
         MSB_SETBIT(64 + 21 * c);
         any_play = true;
@@ -1461,6 +1523,7 @@ struct Engine {
   // The caller guarantees `action` is in legal_actions().  Returns reward | done << 1 as the reference
   // computes them (in registers: no out-pointers behind a non-inlined call).
   MSB_HD MSB_NOINLINE int step(int action) {
+    MSB_SCOPE(PS_STEP);
     int result = 0;
     begin_step();
     int lo = local();

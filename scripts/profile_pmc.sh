@@ -10,7 +10,7 @@ i=0
 shift
 for set in "$@"; do
   i=$((i+1))
-  rocprofv3 --pmc $set --output-format csv -d $OUT/set$i -- python3 $ROOT/bench.py $ARGS > $OUT/bench_$i.json 2> $OUT/err_$i.txt || echo "set $i failed: $set"
+  timeout -k 10 240 rocprofv3 --pmc $set --output-format csv -d $OUT/set$i -- python3 $ROOT/bench.py $ARGS > $OUT/bench_$i.json 2> $OUT/err_$i.txt || echo "set $i failed: $set"
 done
 python3 - <<PY
 import csv,glob,collections
