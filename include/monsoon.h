@@ -125,10 +125,11 @@ int monsoon_rollout(monsoon_t* h, const double* weights, int32_t n_individuals, 
                     int32_t n_matches, const uint8_t* deck_pairs, int32_t n_decks, int32_t max_turns,
                     int32_t* out_counts, int8_t* out_results, int32_t* out_steps);
 
-/* Diagnostics: 128 raw counter words (words 0-4 back monsoon_get_stats; a profiling build (-DMSB_PROF=1,
- * scripts only) adds k_decide phase cycles at 8..15 and per-function cycles / calls at 32..63 / 64..95; the
- * rest is zero).  No reference counterpart. */
-int monsoon_debug_counters(monsoon_t* h, unsigned long long* out128);
+/* Diagnostics: 192 raw counter words (words 0-4 back monsoon_get_stats; a profiling build (-DMSB_PROF=1,
+ * scripts only) adds k_decide phase cycles at 8..15, per-function cycles / calls at 32..63 / 64..95, last-launch
+ * occupancy at 96..101 and call entry / exit cycles at 128..159 / 160..191; the rest is zero).
+ * No reference counterpart. */
+int monsoon_debug_counters(monsoon_t* h, unsigned long long* out192);
 
 /* Device-resident variant used by bench.py: one decision round over the games already loaded by
  * monsoon_reset, weights taken from a table uploaded once.  Nothing crosses PCIe. */

@@ -65,20 +65,18 @@ struct DevBuffers {
   unsigned long long* stats;  // [8]: lookahead, decisions, finished, faults, capacity_faults
   double* scores;      // [cap][156] or null
   double* best;        // [cap]
-  unsigned long long* prof;   // [cap][72] phase cycles, scope cycles, scope calls, profiling build only (else null)
+  int* pop;            // [2] game-index counters of the persistent k_decide, alternating between launches
+  unsigned long long* prof;   // [cap][..] phase cycles, scope cycles, scope calls (profiling build), profiling build only (else null)
 };
 
-enum { ST_LOOKAHEAD = 0, ST_DECISIONS = 1, ST_FINISHED = 2, ST_FAULTS = 3, ST_CAPFAULTS = 4, ST_PROF = 8, ST_WORDS = 32, PROF_WORDS = 74 };
+enum { ST_LOOKAHEAD = 0, ST_DECISIONS = 1, ST_FINISHED = 2, ST_FAULTS = 3, ST_CAPFAULTS = 4, ST_PROF = 8, ST_WORDS = 32, PROF_WORDS = 138 };
 // Phase timing of k_decide (profiling build only, -DMSB_PROF=1 -> libmonsoon_hip_prof.so; never the product):
 // wave cycles per phase accumulated into stats[ST_PROF + phase].
 #if defined(MSB_PROF) && MSB_PROF
 #define PROF_DECL()                                                                                   \
   unsigned long long prof_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};                                          \
   const unsigned long long prof_wall0 = wall_clock64();                                               \
-  if (lane < 32) {                                                                                    \
-    *(MSB_AS_LDS unsigned long long*)(uintptr_t)(MSB_PROF_LDS + 8 * lane) = 0ull;                     \
-    *(MSB_AS_LDS unsigned*)(uintptr_t)(MSB_PROF_LDS + 256 + 4 * lane) = 0u;                           \
-  }                                                                                                   \
+  for (int i_ = lane; i_ < (928 - 16) / 4; i_ += 64) *(MSB_AS_LDS unsigned*)(uintptr_t)(MSB_PROF_LDS + 4 * i_) = 0u; \
   __syncthreads();                                                                                    \
   unsigned long long prof_t = __builtin_readcyclecounter()
 #define PROF_MARK(ph)                                         \
@@ -93,12 +91,14 @@ enum { ST_LOOKAHEAD = 0, ST_DECISIONS = 1, ST_FINISHED = 2, ST_FAULTS = 3, ST_CA
     if (lane == 0)                                                          \
       for (int i_ = 0; i_ < 8; i_++) b.prof[(size_t)g * PROF_WORDS + i_] += prof_acc[i_]; \
     if (lane == 0) {                                                        \
-      b.prof[(size_t)g * PROF_WORDS + 72] = prof_wall0;                     \
-      b.prof[(size_t)g * PROF_WORDS + 73] = wall_clock64();                 \
+      b.prof[(size_t)g * PROF_WORDS + 136] = prof_wall0;                    \
+      b.prof[(size_t)g * PROF_WORDS + 137] = wall_clock64();                \
     }                                                                       \
     if (lane < 32) {                                                        \
       b.prof[(size_t)g * PROF_WORDS + 8 + lane] += *(MSB_AS_LDS unsigned long long*)(uintptr_t)(MSB_PROF_LDS + 8 * lane); \
       b.prof[(size_t)g * PROF_WORDS + 40 + lane] += *(MSB_AS_LDS unsigned*)(uintptr_t)(MSB_PROF_LDS + 256 + 4 * lane);   \
+      b.prof[(size_t)g * PROF_WORDS + 72 + lane] += *(MSB_AS_LDS unsigned long long*)(uintptr_t)(MSB_PROF_LDS + 384 + 8 * lane); \
+      b.prof[(size_t)g * PROF_WORDS + 104 + lane] += *(MSB_AS_LDS unsigned long long*)(uintptr_t)(MSB_PROF_LDS + 640 + 8 * lane); \
     }                                                                       \
   } while (0)
 #else
@@ -191,7 +191,7 @@ constexpr int API_LANES = 64;
 // LDS address 0 is avoided on purpose: an integer constant 0 cast to an LDS pointer is the null pointer,
 // which is not address 0 on this target; every region starts at LDS_ORIGIN.
 #if defined(MSB_PROF) && MSB_PROF
-constexpr int LDS_ORIGIN = 400;   // [16,400): function-scope counters of the profiling build (msb_base.h)
+constexpr int LDS_ORIGIN = 928;   // [16,928): function-scope counters of the profiling build (msb_base.h)
 #else
 constexpr int LDS_ORIGIN = 16;
 #endif
@@ -391,14 +391,12 @@ struct DecideLds {
   static constexpr int TOTAL = WF + 160;
 };
 
-template <int U, int WPE>
-__global__ void __launch_bounds__(64, WPE) k_decide(DevBuffers b, int n, int max_turns, int write_scores) {
+// One decision of game g by the calling wavefront.
+template <int U>
+__device__ void decide_game(const DevBuffers& b, const int g, const int lane, int max_turns, int write_scores) {
   typedef DecideLds<U> L;
   typedef Engine<SharedMem<L::PAR>> ParEngine;
   typedef Engine<LaneMem<U, L::PRIV>> CandEngine;
-  const int g = blockIdx.x;
-  const int lane = threadIdx.x;
-  if (g >= n) return;
   GameMeta meta = b.meta[g];
   if (meta.result != -2) {
     if (lane == 0) {
@@ -568,6 +566,26 @@ __global__ void __launch_bounds__(64, WPE) k_decide(DevBuffers b, int n, int max
   PROF_FLUSH();
 }
 
+// Hot kernel.  Persistent wavefronts: the grid is what the GPU holds at once; a wavefront plays game blockIdx.x and
+// then pops further game indices from a counter (the pop is issued before the current game is played, so its
+// latency is hidden).  Games stay in index order -- neighbouring records, stream blocks and meta rows are touched
+// together; sorting the games by expected cost was measured 5-8 % slower -- and no workgroup is launched per
+// game.  Every wave reaches the exit (t >= n): the counter only grows.  counters[parity] is this launch's
+// counter; the other one is cleared for the next launch.  persistent = 0: one workgroup per game.
+template <int U, int WPE>
+__global__ void __launch_bounds__(64, WPE) k_decide(DevBuffers b, int n, int max_turns, int write_scores, int persistent, int parity) {
+  const int lane = threadIdx.x;
+  if (blockIdx.x == 0 && lane == 0) b.pop[parity ^ 1] = 0;
+  int t = blockIdx.x;
+  while (t < n) {
+    int nxt = 0x7fffffff;
+    if (persistent && lane == 0) nxt = (int)gridDim.x + atomicAdd(&b.pop[parity], 1);
+    decide_game<U>(b, t, lane, max_turns, write_scores);
+    __syncthreads();   // the LDS image is reused by the next game
+    t = __builtin_amdgcn_readfirstlane(nxt);
+  }
+}
+
 __global__ void k_clear_scores(double* scores, size_t n) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) scores[i] = NAN;
@@ -617,6 +635,8 @@ struct monsoon {
   hipStream_t stream;
   DevBuffers b;
   int wpe;            // k_decide variant: __launch_bounds__ waves per SIMD
+  int parity;         // which of b.pop the next k_decide launch uses
+  int grid_waves;     // persistent grid size of k_decide (resident wavefronts), 0 = not yet queried
   int n;              // games loaded by the last reset
   int n_individuals;
   std::string err;
@@ -687,7 +707,7 @@ const char* monsoon_last_error(monsoon_t* h) { return h ? h->err.c_str() : g_cre
 void monsoon_destroy(monsoon_t* h) {
   if (!h) return;
   hipSetDevice(h->device);
-  void* ptrs[] = {h->b.state, h->b.rng_out, h->b.rng_mt, h->b.meta, h->b.weights, h->b.stats, h->b.scores, h->b.best, h->b.prof,
+  void* ptrs[] = {h->b.state, h->b.rng_out, h->b.rng_mt, h->b.meta, h->b.weights, h->b.stats, h->b.scores, h->b.best, h->b.prof, h->b.pop,
                   h->d_bytes, h->d_decks, h->d_factions, h->d_seeds, h->d_masks, h->d_i32, h->d_f64, h->d_p1, h->d_p2, h->d_int};
   for (void* p : ptrs)
     if (p) hipFree(p);
@@ -734,6 +754,8 @@ int monsoon_create(const monsoon_config* cfg, monsoon_t** out) {
   h->d_i32 = nullptr; h->d_f64 = nullptr; h->d_p1 = nullptr; h->d_p2 = nullptr; h->d_int = nullptr;
   h->kernel_ms = 0;
   h->kernel_launches = 0;
+  h->parity = 0;
+  h->grid_waves = 0;
   *out = h;
   size_t cap = (size_t)cfg->max_games;
   HIP_TRY(h, hipSetDevice(h->device));
@@ -748,6 +770,8 @@ int monsoon_create(const monsoon_config* cfg, monsoon_t** out) {
   HIP_TRY(h, hipMalloc(&h->b.stats, ST_WORDS * sizeof(unsigned long long)));
   HIP_TRY(h, hipMemset(h->b.stats, 0, ST_WORDS * sizeof(unsigned long long)));
   HIP_TRY(h, hipMalloc(&h->b.best, cap * sizeof(double)));
+  HIP_TRY(h, hipMalloc(&h->b.pop, 2 * sizeof(int)));
+  HIP_TRY(h, hipMemset(h->b.pop, 0, 2 * sizeof(int)));
 #if defined(MSB_PROF) && MSB_PROF
   HIP_TRY(h, hipMalloc(&h->b.prof, cap * PROF_WORDS * sizeof(unsigned long long)));
   HIP_TRY(h, hipMemset(h->b.prof, 0, cap * PROF_WORDS * sizeof(unsigned long long)));
@@ -996,10 +1020,24 @@ static int launch_decide(monsoon_t* h, int n, int max_turns, int write_scores, b
   if (timed) {
     HIP_TRY(h, hipEventCreate(&e0));
     HIP_TRY(h, hipEventCreate(&e1));
-    HIP_TRY(h, hipEventRecord(e0, h->stream));
   }
+  static const int persistent = getenv("MONSOON_PERSIST") ? atoi(getenv("MONSOON_PERSIST")) : 1;
   static const int lds_pad = getenv("MONSOON_LDS_PAD") ? atoi(getenv("MONSOON_LDS_PAD")) : 0;   // occupancy experiments only
-#define MSB_LAUNCH(U, W) hipLaunchKernelGGL((k_decide<U, W>), dim3(n), dim3(64), DecideLds<U>::TOTAL + lds_pad, h->stream, h->b, n, max_turns, write_scores)
+  if (timed) HIP_TRY(h, hipEventRecord(e0, h->stream));
+#define MSB_LAUNCH(U, W)                                                                                                \
+  do {                                                                                                                  \
+    if (!h->grid_waves) {                                                                                               \
+      int per_cu = 0;                                                                                                   \
+      hipDeviceProp_t prop;                                                                                             \
+      HIP_TRY(h, hipGetDeviceProperties(&prop, h->device));                                                             \
+      HIP_TRY(h, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_decide<U, W>, 64, DecideLds<U>::TOTAL + lds_pad)); \
+      h->grid_waves = per_cu > 0 ? per_cu * prop.multiProcessorCount : 4096;                                            \
+      if (const char* e = getenv("MONSOON_GRID")) h->grid_waves = atoi(e);                                              \
+    }                                                                                                                   \
+    int grid = (persistent && h->grid_waves < n) ? h->grid_waves : n;                                                   \
+    hipLaunchKernelGGL((k_decide<U, W>), dim3(grid), dim3(64), DecideLds<U>::TOTAL + lds_pad, h->stream, h->b, n, max_turns, write_scores, persistent, h->parity); \
+    h->parity ^= 1; \
+  } while (0)
   int variant = h->cfg.lanes_per_game * 10 + h->wpe;
   switch (variant) {
     case 81: MSB_LAUNCH(8, 1); break;
@@ -1182,11 +1220,11 @@ int monsoon_get_stats(monsoon_t* h, monsoon_stats* out) {
   return MONSOON_OK;
 }
 
-// Raw counter words; out = 128 u64 (profiling builds: k_decide phase cycles at 8.., function scopes at 32.. / 64..).
+// Raw counter words; out = 192 u64 (profiling builds: k_decide phase cycles at 8.., function scopes at 32.. / 64..).
 int monsoon_debug_counters(monsoon_t* h, unsigned long long* out) {
   if (!h || !out) return MONSOON_ERR_ARG;
   HIP_TRY(h, hipStreamSynchronize(h->stream));
-  memset(out, 0, 128 * sizeof(unsigned long long));
+  memset(out, 0, 192 * sizeof(unsigned long long));
   HIP_TRY(h, hipMemcpy(out, h->b.stats, ST_WORDS * sizeof(unsigned long long), hipMemcpyDeviceToHost));
 #if defined(MSB_PROF) && MSB_PROF
   {
@@ -1195,15 +1233,16 @@ int monsoon_debug_counters(monsoon_t* h, unsigned long long* out) {
     for (size_t i = 0; i < v.size(); i++) {
       size_t k = i % PROF_WORDS;
       if (k < 72) out[k < 8 ? ST_PROF + k : 32 + (k - 8)] += v[i];   // 32..63 scope cycles, 64..95 scope calls
+      else if (k < 136) out[128 + (k - 72)] += v[i];                 // 128..159 call-entry cycles, 160..191 call-exit cycles
     }
     // occupancy of the LAST launch from the per-wave wall-clock stamps (100 MHz): span, sum of wave times,
     // time at which the 4096th-from-last wave ended (start of the tail)
     {
       std::vector<unsigned long long> st, en;
       unsigned long long newest = 0;
-      for (int g = 0; g < h->n; g++) newest = std::max(newest, v[(size_t)g * PROF_WORDS + 73]);
+      for (int g = 0; g < h->n; g++) newest = std::max(newest, v[(size_t)g * PROF_WORDS + 137]);
       for (int g = 0; g < h->n; g++) {
-        unsigned long long a = v[(size_t)g * PROF_WORDS + 72], e = v[(size_t)g * PROF_WORDS + 73];
+        unsigned long long a = v[(size_t)g * PROF_WORDS + 136], e = v[(size_t)g * PROF_WORDS + 137];
         if (e > a && e + 1000000ull > newest) {   // stamps of the last launch only (within 10 ms of the newest)
           st.push_back(a);
           en.push_back(e);

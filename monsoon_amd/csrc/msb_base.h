@@ -22,26 +22,55 @@
 // Function-level timing scopes of the profiling build (-DMSB_PROF=1, scripts/phase_profile.py only): the leader
 // lane of whatever sub-wave executes a function adds the elapsed wave cycles to an LDS counter.  Inclusive
 // times; nested/recursive scopes count twice.  Expands to nothing in the product and in the oracle.
-#define MSB_PROF_LDS 16          // u64 cycles[32] then u32 calls[32]; the records start at 400 in that build
+#define MSB_PROF_LDS 16          // u64 cycles[32], u32 calls[32], u64 entry[32], u64 exit[32], two u64 stamps; records start at 928
 #if defined(MSB_PROF) && MSB_PROF && defined(__HIP_DEVICE_COMPILE__)
+typedef __attribute__((address_space(3))) unsigned long long* msb_lds64;
+typedef __attribute__((address_space(3))) unsigned* msb_lds32;
+__device__ inline __attribute__((always_inline)) bool msb_prof_leader() {
+  unsigned l = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+  return (unsigned)__builtin_amdgcn_readfirstlane((int)l) == l;
+}
 struct ProfScope {
   unsigned long long t0;
   int id;
-  __device__ inline __attribute__((always_inline)) explicit ProfScope(int i) : t0(__builtin_readcyclecounter()), id(i) {}
+  __device__ inline __attribute__((always_inline)) explicit ProfScope(int i) : t0(__builtin_readcyclecounter()), id(i) {
+    // time since the caller's MSB_PRECALL stamp = call + prologue (callee-saved register saves)
+    if (msb_prof_leader()) {
+      unsigned long long pre = *(msb_lds64)(unsigned long)(MSB_PROF_LDS + 896);
+      if (pre) {
+        __hip_atomic_fetch_add((msb_lds64)(unsigned long)(MSB_PROF_LDS + 384 + 8 * id), t0 - pre, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        *(msb_lds64)(unsigned long)(MSB_PROF_LDS + 896) = 0ull;
+      }
+    }
+  }
   __device__ inline __attribute__((always_inline)) ~ProfScope() {
-    unsigned long long dt = __builtin_readcyclecounter() - t0;
-    unsigned l = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
-    if ((unsigned)__builtin_amdgcn_readfirstlane((int)l) == l) {
-      typedef __attribute__((address_space(3))) unsigned long long* lds64;
-      typedef __attribute__((address_space(3))) unsigned* lds32;
-      __hip_atomic_fetch_add((lds64)(unsigned long)(MSB_PROF_LDS + 8 * id), dt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-      __hip_atomic_fetch_add((lds32)(unsigned long)(MSB_PROF_LDS + 256 + 4 * id), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    unsigned long long now = __builtin_readcyclecounter();
+    if (msb_prof_leader()) {
+      __hip_atomic_fetch_add((msb_lds64)(unsigned long)(MSB_PROF_LDS + 8 * id), now - t0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      __hip_atomic_fetch_add((msb_lds32)(unsigned long)(MSB_PROF_LDS + 256 + 4 * id), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      *(msb_lds64)(unsigned long)(MSB_PROF_LDS + 904) = now;   // the epilogue starts here
     }
   }
 };
 #define MSB_SCOPE(id) ProfScope msb_prof_scope_(id)
+#define MSB_PRECALL()                                                                                   \
+  do {                                                                                                  \
+    if (msb_prof_leader()) *(msb_lds64)(unsigned long)(MSB_PROF_LDS + 896) = __builtin_readcyclecounter(); \
+  } while (0)
+#define MSB_POSTCALL(id)                                                                                \
+  do {                                                                                                  \
+    unsigned long long now_ = __builtin_readcyclecounter();                                             \
+    if (msb_prof_leader()) {                                                                            \
+      unsigned long long post_ = *(msb_lds64)(unsigned long)(MSB_PROF_LDS + 904);                       \
+      if (post_ && now_ > post_)                                                                        \
+        __hip_atomic_fetch_add((msb_lds64)(unsigned long)(MSB_PROF_LDS + 640 + 8 * (id)), now_ - post_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); \
+      *(msb_lds64)(unsigned long)(MSB_PROF_LDS + 904) = 0ull;                                           \
+    }                                                                                                   \
+  } while (0)
 #else
 #define MSB_SCOPE(id)
+#define MSB_PRECALL() do {} while (0)
+#define MSB_POSTCALL(id) do {} while (0)
 #endif
 enum {
   PS_STEP, PS_PLAYER_PLAY, PS_NEW_ENTITY, PS_RUN_ABILITY, PS_ABILITY_ENTITY, PS_ABILITY_SPELL, PS_GET_TARGETS, PS_SHAPE_TILES,

@@ -465,7 +465,13 @@ struct Engine {
     if (REM_LISTS) rem_collect(used);
     m.st8(H_DEPTH, 0);
   }
-  MSB_HD MSB_NOINLINE int new_entity(int card, int owner, int strength, int movement, bool ff) {
+  MSB_HD MSB_INL int new_entity(int card, int owner, int strength, int movement, bool ff) {
+    MSB_PRECALL();
+    int r_ = new_entity_impl(card, owner, strength, movement, ff);
+    MSB_POSTCALL(PS_NEW_ENTITY);
+    return r_;
+  }
+  MSB_HD MSB_NOINLINE int new_entity_impl(int card, int owner, int strength, int movement, bool ff) {
     MSB_SCOPE(PS_NEW_ENTITY);
     int e = alloc_entity();
     if (fault()) return e;
@@ -596,7 +602,13 @@ struct Engine {
   MSB_HD MSB_INL void recalc_front_after_destroy() { calculate_front_line(opponent_of(cp())); }
 
   // Board.get_targets, board.py:147-204
-  MSB_HD MSB_NOINLINE PList get_targets(int pov, Tgt t, int exclude_pk) {
+  MSB_HD MSB_INL PList get_targets(int pov, Tgt t, int exclude_pk) {
+    MSB_PRECALL();
+    PList r_ = get_targets_impl(pov, t, exclude_pk);
+    MSB_POSTCALL(PS_GET_TARGETS);
+    return r_;
+  }
+  MSB_HD MSB_NOINLINE PList get_targets_impl(int pov, Tgt t, int exclude_pk) {
     MSB_SCOPE(PS_GET_TARGETS);
     PList out;
     out.clear();
@@ -840,7 +852,13 @@ struct Engine {
   }
   // wrapped activate_ability.  subj >= 0: entity slot.  subj < 0: a spell, spell_card/spell_owner
   // passed in `spell`.  The trailing pop_trigger() is a tail call in the reference, hence a loop.
-  MSB_HD MSB_NOINLINE void run_ability(int e, int spell, int pos_pk, bool src) {
+  MSB_HD MSB_INL void run_ability(int e, int spell, int pos_pk, bool src) {
+    MSB_PRECALL();
+    run_ability_impl(e, spell, pos_pk, src);
+    MSB_POSTCALL(PS_RUN_ABILITY);
+    
+  }
+  MSB_HD MSB_NOINLINE void run_ability_impl(int e, int spell, int pos_pk, bool src) {
     MSB_SCOPE(PS_RUN_ABILITY);
     int d = m.ld8(H_DEPTH);
     if (d >= MAX_DEPTH) {
@@ -850,9 +868,11 @@ struct Engine {
     m.st8(H_DEPTH, d + 1);
     for (;;) {
       m.st8(H_RESOLVING, 1);
-      if (e >= 0)
+      if (e >= 0) {
+        MSB_PRECALL();
         ability_entity(e, pos_pk, src);
-      else
+        MSB_POSTCALL(PS_ABILITY_ENTITY);
+      } else
         ability_spell(spell & 0xff, spell >> 8, pos_pk);
       if (fault()) break;
       m.st8(H_RESOLVING, 0);
@@ -883,7 +903,13 @@ struct Engine {
   MSB_HD MSB_INL void player_heal(int order, int amount) { set_pl_base(order, pl_base(order) + amount); }
 
   // Unit.deal_damage unit.py:205-219 / Structure.deal_damage structure.py:52-63
-  MSB_HD MSB_NOINLINE int entity_deal_damage(int e, int amount, bool pending, bool src) {
+  MSB_HD MSB_INL int entity_deal_damage(int e, int amount, bool pending, bool src) {
+    MSB_PRECALL();
+    int r_ = entity_deal_damage_impl(e, amount, pending, src);
+    MSB_POSTCALL(PS_DEAL_DAMAGE);
+    return r_;
+  }
+  MSB_HD MSB_NOINLINE int entity_deal_damage_impl(int e, int amount, bool pending, bool src) {
     MSB_SCOPE(PS_DEAL_DAMAGE);
     int s = e_str(e);
     if (s - amount < 0) amount = s;
@@ -916,7 +942,13 @@ struct Engine {
       e_set_str(who, e_str(who) + amount);
   }
   // Unit.destroy unit.py:221-231 / Structure.destroy structure.py:65-69
-  MSB_HD MSB_NOINLINE void destroy(int e, bool src) {
+  MSB_HD MSB_INL void destroy(int e, bool src) {
+    MSB_PRECALL();
+    destroy_impl(e, src);
+    MSB_POSTCALL(PS_DESTROY);
+    
+  }
+  MSB_HD MSB_NOINLINE void destroy_impl(int e, bool src) {
     MSB_SCOPE(PS_DESTROY);
     if (e_is_unit(e)) {
       board_set(e_pos(e), -1);
@@ -969,7 +1001,13 @@ struct Engine {
   // Movement
   // ------------------------------------------------------------------------------------------
   // Unit.set_path, unit.py:78-122
-  MSB_HD MSB_NOINLINE void set_path(int e, bool on_play) {
+  MSB_HD MSB_INL void set_path(int e, bool on_play) {
+    MSB_PRECALL();
+    set_path_impl(e, on_play);
+    MSB_POSTCALL(PS_SET_PATH);
+    
+  }
+  MSB_HD MSB_NOINLINE void set_path_impl(int e, bool on_play) {
     MSB_SCOPE(PS_SET_PATH);
     P position = e_pos(e);
     int confused_cached = e_st(e, ST_CONFUSED);
@@ -1038,7 +1076,13 @@ struct Engine {
   }
 
   // Unit.move, unit.py:124-203
-  MSB_HD MSB_NOINLINE void move(int e) {
+  MSB_HD MSB_INL void move(int e) {
+    MSB_PRECALL();
+    move_impl(e);
+    MSB_POSTCALL(PS_MOVE);
+    
+  }
+  MSB_HD MSB_NOINLINE void move_impl(int e) {
     MSB_SCOPE(PS_MOVE);
     int d = m.ld8(H_DEPTH);
     if (d >= MAX_DEPTH) {
@@ -1344,7 +1388,13 @@ struct Engine {
     }
   }
   // Player.play, player.py:68-77.  has_pos=false <=> position None
-  MSB_HD MSB_NOINLINE void player_play(int o, int index, P position, bool has_pos) {
+  MSB_HD MSB_INL void player_play(int o, int index, P position, bool has_pos) {
+    MSB_PRECALL();
+    player_play_impl(o, index, position, has_pos);
+    MSB_POSTCALL(PS_PLAYER_PLAY);
+    
+  }
+  MSB_HD MSB_NOINLINE void player_play_impl(int o, int index, P position, bool has_pos) {
     MSB_SCOPE(PS_PLAYER_PLAY);
     int card = hand_card(o, index), fl = hand_flags(o, index);
     int strength = inst_strength(card, fl, hand_x(o, index));   // target.copy() copies the instance's strength
@@ -1522,7 +1572,13 @@ struct Engine {
   // Stormbound.step, games/stormbound.py:318-373 (without the observation; see observe.inc).
   // The caller guarantees `action` is in legal_actions().  Returns reward | done << 1 as the reference
   // computes them (in registers: no out-pointers behind a non-inlined call).
-  MSB_HD MSB_NOINLINE int step(int action) {
+  MSB_HD MSB_INL int step(int action) {
+    MSB_PRECALL();
+    int r_ = step_impl(action);
+    MSB_POSTCALL(PS_STEP);
+    return r_;
+  }
+  MSB_HD MSB_NOINLINE int step_impl(int action) {
     MSB_SCOPE(PS_STEP);
     int result = 0;
     begin_step();

@@ -42,7 +42,7 @@ def main():
     for _ in range(args.steps):
         eng.decide_round()
     eng.sync()
-    c = np.zeros(128, dtype=np.uint64)
+    c = np.zeros(192, dtype=np.uint64)
     eng._ck(eng.lib.monsoon_debug_counters(eng.h, c.ctypes.data_as(ctypes.c_void_p)), "counters")
     look, dec = int(c[0]), int(c[1])
     ph = c[8:16].astype(np.float64)
@@ -57,10 +57,13 @@ def main():
         print(f"last launch (100 MHz wall clock): span {span / 100:.1f} us, {int(nw)} waves, mean wave {total / nw / 100:.1f} us, longest {longest / 100:.1f} us")
         print(f"  resident-wave average {total / span:.0f} of 4096; last wave started at {last_start / 100:.1f} us; 4096th-from-last wave ended at {tail0 / 100:.1f} us")
     print("function scopes (inclusive wave cycles of the sub-wave executing them; nested scopes count twice):")
-    rows = sorted(zip(SCOPES, c[32:32 + len(SCOPES)].astype(float), c[64:64 + len(SCOPES)].astype(float)), key=lambda r: -r[1])
-    for name, cyc, calls in rows:
+    k = len(SCOPES)
+    rows = sorted(zip(SCOPES, c[32:32 + k].astype(float), c[64:64 + k].astype(float), c[128:128 + k].astype(float), c[160:160 + k].astype(float)),
+                  key=lambda r: -r[1])
+    for name, cyc, calls, ent, ext in rows:
         if calls:
-            print(f"  {name:16s} {cyc / dec:10.0f} cycles/decision {100 * cyc / tot:5.1f} %  {calls / dec:7.2f} calls/decision {cyc / calls:8.0f} cycles/call")
+            extra = f"  entry {ent / calls:6.0f} exit {ext / calls:6.0f} cycles/call ({100 * (ent + ext) / tot:4.1f} % of all)" if ent or ext else ""
+            print(f"  {name:16s} {cyc / dec:10.0f} cycles/decision {100 * cyc / tot:5.1f} %  {calls / dec:7.2f} calls/decision {cyc / calls:8.0f} cycles/call{extra}")
 
 
 SCOPES = ["step", "player_play", "new_entity", "run_ability", "ability_entity", "ability_spell", "get_targets", "shape_tiles",
