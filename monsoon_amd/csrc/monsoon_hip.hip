@@ -48,9 +48,9 @@ struct GameMeta {
   int8_t result;           // -2 running, -1 draw, 0 FIRST won, 1 SECOND won
   uint8_t fault;
   uint8_t last_action;
-  uint8_t pad;
-  uint16_t steps;          // committed decisions
-  uint16_t pad2;
+  uint8_t flags;           // b0: ended with a winner (have_winner), as opposed to max_turns / a fault
+  uint16_t steps;          // committed steps (decisions and monsoon_step calls)
+  uint16_t decided;        // decisions committed by k_decide
   uint32_t rng;            // cursor (bits 0-15) | current block (bit 16)
   uint32_t lookahead;      // look-ahead transitions executed for this game
   uint32_t match;          // schedule index (rollout)
@@ -65,7 +65,7 @@ struct DevBuffers {
   unsigned long long* stats;  // [8]: lookahead, decisions, finished, faults, capacity_faults
   double* scores;      // [cap][156] or null
   double* best;        // [cap]
-  int* pop;            // [2] game-index counters of the persistent k_decide, alternating between launches
+  int* pop;            // [2][POP_PARTS * POP_STRIDE] game-index counters of the persistent k_decide, alternating between launches
   unsigned long long* prof;   // [cap][..] phase cycles, scope cycles, scope calls (profiling build), profiling build only (else null)
 };
 
@@ -425,8 +425,8 @@ __device__ void decide_game(const DevBuffers& b, const int g, const int lane, in
       if (pe.have_winner()) res = (b1 < 0 && b0 >= 0) ? 0 : (b0 < 0 && b1 >= 0) ? 1 : -1;
       meta.result = (int8_t)res;
       meta.last_action = 255;
+      if (pe.have_winner()) meta.flags |= 1;
       b.meta[g] = meta;
-      if (pe.have_winner()) atomicAdd(&b.stats[ST_FINISHED], 1ull);
       if (b.best) b.best[g] = NAN;
     }
     return;
@@ -550,14 +550,11 @@ __device__ void decide_game(const DevBuffers& b, const int g, const int lane, in
     meta.last_action = (uint8_t)A;
     int executed = n_legal;   // every legal action is stepped exactly once; the commit re-executes nothing
     meta.lookahead += (uint32_t)executed;
-    atomicAdd(&b.stats[ST_LOOKAHEAD], (unsigned long long)executed);
-    atomicAdd(&b.stats[ST_DECISIONS], 1ull);
+    meta.decided++;   // statistics are per-game fields reduced on demand (k_stats): no same-address atomics here
     if (cfault) {
       // evo/fitness.py:208-210: an exception while applying the action ends the game as a draw
       meta.fault = (uint8_t)cfault;
       meta.result = -1;
-      atomicAdd(&b.stats[ST_FAULTS], 1ull);
-      if (cfault >= FAULT_CAPACITY) atomicAdd(&b.stats[ST_CAPFAULTS], 1ull);
     }
     b.meta[g] = meta;
     if (b.best) b.best[g] = rs;
@@ -566,23 +563,56 @@ __device__ void decide_game(const DevBuffers& b, const int g, const int lane, in
   PROF_FLUSH();
 }
 
-// Hot kernel.  Persistent wavefronts: the grid is what the GPU holds at once; a wavefront plays game blockIdx.x and
-// then pops further game indices from a counter (the pop is issued before the current game is played, so its
-// latency is hidden).  Games stay in index order -- neighbouring records, stream blocks and meta rows are touched
-// together; sorting the games by expected cost was measured 5-8 % slower -- and no workgroup is launched per
-// game.  Every wave reaches the exit (t >= n): the counter only grows.  counters[parity] is this launch's
-// counter; the other one is cleared for the next launch.  persistent = 0: one workgroup per game.
+// Hot kernel.  Persistent wavefronts: the grid is what the GPU holds at once.  The games are split into
+// POP_PARTS contiguous ranges; wavefront w works on range w % POP_PARTS (workgroups are dealt to the 8 XCDs round-
+// robin, so a range stays on one XCD and its L2): it starts with the game given by its index and then pops further
+// ones from the range's counter, the pop being issued before the current game is played so that its latency is
+// hidden.  Games stay in index order -- neighbouring records, stream blocks and meta rows are touched together;
+// sorting the games by expected cost was measured 5-8 % slower.  One counter per range, 128 bytes apart: atomics
+// on ONE address serialise at ~25 ns each, which capped the whole launch at 65 536 x 25 ns (the same trap as
+// per-game statistics counters; see k_stats).  Every wave reaches its exit (t >= hi): counters only grow.
+// b.pop[parity] is this launch's set; the other one is cleared for the next launch.  persistent = 0: one workgroup
+// per game.
+constexpr int POP_PARTS = 8, POP_STRIDE = 32;
 template <int U, int WPE>
 __global__ void __launch_bounds__(64, WPE) k_decide(DevBuffers b, int n, int max_turns, int write_scores, int persistent, int parity) {
   const int lane = threadIdx.x;
-  if (blockIdx.x == 0 && lane == 0) b.pop[parity ^ 1] = 0;
-  int t = blockIdx.x;
-  while (t < n) {
+  if (!persistent) {
+    if ((int)blockIdx.x < n) decide_game<U>(b, blockIdx.x, lane, max_turns, write_scores);
+    return;
+  }
+  int* mine = b.pop + parity * POP_PARTS * POP_STRIDE;
+  int* other = b.pop + (parity ^ 1) * POP_PARTS * POP_STRIDE;
+  if (blockIdx.x == 0 && lane < POP_PARTS) other[lane * POP_STRIDE] = 0;
+  const int part = blockIdx.x % POP_PARTS, rank = blockIdx.x / POP_PARTS;
+  const int waves = ((int)gridDim.x - part + POP_PARTS - 1) / POP_PARTS;   // wavefronts working on this range
+  const int lo = (int)((long long)n * part / POP_PARTS), hi = (int)((long long)n * (part + 1) / POP_PARTS);
+  int t = lo + rank;
+  while (t < hi) {
     int nxt = 0x7fffffff;
-    if (persistent && lane == 0) nxt = (int)gridDim.x + atomicAdd(&b.pop[parity], 1);
+    if (lane == 0) nxt = lo + waves + atomicAdd(&mine[part * POP_STRIDE], 1);
     decide_game<U>(b, t, lane, max_turns, write_scores);
     __syncthreads();   // the LDS image is reused by the next game
     t = __builtin_amdgcn_readfirstlane(nxt);
+  }
+}
+
+// Statistics of the loaded games, reduced from the per-game fields: {look-ahead steps, decisions, games ended by a
+// winner, games stopped by a fault, of those build-limit faults}.  One atomic per wavefront into a zeroed buffer.
+__global__ void __launch_bounds__(256) k_stats(DevBuffers b, int n, unsigned long long* out) {
+  unsigned long long v[5] = {0, 0, 0, 0, 0};
+  for (int g = blockIdx.x * blockDim.x + threadIdx.x; g < n; g += gridDim.x * blockDim.x) {
+    GameMeta m = b.meta[g];
+    v[0] += m.lookahead;
+    v[1] += m.decided;
+    v[2] += (m.flags & 1) ? 1 : 0;
+    v[3] += (m.result == -1 && m.fault) ? 1 : 0;
+    v[4] += (m.result == -1 && m.fault >= FAULT_CAPACITY) ? 1 : 0;
+  }
+  for (int i = 0; i < 5; i++) {
+    unsigned long long x = v[i];
+    for (int off = 32; off >= 1; off >>= 1) x += __shfl_xor(x, off);
+    if ((threadIdx.x & 63) == 0 && x) atomicAdd(&out[i], x);
   }
 }
 
@@ -636,6 +666,7 @@ struct monsoon {
   DevBuffers b;
   int wpe;            // k_decide variant: __launch_bounds__ waves per SIMD
   int parity;         // which of b.pop the next k_decide launch uses
+  unsigned long long st_acc[5], st_base[5];   // statistics: totals of earlier batches, baseline of the loaded one
   int grid_waves;     // persistent grid size of k_decide (resident wavefronts), 0 = not yet queried
   int n;              // games loaded by the last reset
   int n_individuals;
@@ -756,6 +787,8 @@ int monsoon_create(const monsoon_config* cfg, monsoon_t** out) {
   h->kernel_launches = 0;
   h->parity = 0;
   h->grid_waves = 0;
+  memset(h->st_acc, 0, sizeof(h->st_acc));
+  memset(h->st_base, 0, sizeof(h->st_base));
   *out = h;
   size_t cap = (size_t)cfg->max_games;
   HIP_TRY(h, hipSetDevice(h->device));
@@ -770,8 +803,8 @@ int monsoon_create(const monsoon_config* cfg, monsoon_t** out) {
   HIP_TRY(h, hipMalloc(&h->b.stats, ST_WORDS * sizeof(unsigned long long)));
   HIP_TRY(h, hipMemset(h->b.stats, 0, ST_WORDS * sizeof(unsigned long long)));
   HIP_TRY(h, hipMalloc(&h->b.best, cap * sizeof(double)));
-  HIP_TRY(h, hipMalloc(&h->b.pop, 2 * sizeof(int)));
-  HIP_TRY(h, hipMemset(h->b.pop, 0, 2 * sizeof(int)));
+  HIP_TRY(h, hipMalloc(&h->b.pop, 2 * 8 * 32 * sizeof(int)));
+  HIP_TRY(h, hipMemset(h->b.pop, 0, 2 * 8 * 32 * sizeof(int)));
 #if defined(MSB_PROF) && MSB_PROF
   HIP_TRY(h, hipMalloc(&h->b.prof, cap * PROF_WORDS * sizeof(unsigned long long)));
   HIP_TRY(h, hipMemset(h->b.prof, 0, cap * PROF_WORDS * sizeof(unsigned long long)));
@@ -808,6 +841,8 @@ static int launch_reset(monsoon_t* h, int n) {
   return MONSOON_OK;
 }
 
+static int fold_stats(monsoon_t* h);
+
 int monsoon_reset(monsoon_t* h, int32_t n, const uint32_t* seeds, const uint8_t* decks, const uint8_t* factions) {
   if (!h || !seeds || !decks || n <= 0 || n > h->cfg.max_games) {
     if (h) h->err = "monsoon_reset: bad argument";
@@ -821,6 +856,10 @@ int monsoon_reset(monsoon_t* h, int32_t n, const uint32_t* seeds, const uint8_t*
     }
   }
   HIP_TRY(h, hipSetDevice(h->device));
+  {
+    int rc = fold_stats(h);   // statistics live in the per-game rows that are about to be cleared
+    if (rc) return rc;
+  }
   HIP_TRY(h, hipMemcpyAsync(h->d_seeds, seeds, (size_t)n * 4, hipMemcpyHostToDevice, h->stream));
   HIP_TRY(h, hipMemcpyAsync(h->d_decks, decks, (size_t)n * 24, hipMemcpyHostToDevice, h->stream));
   if (factions)
@@ -1031,7 +1070,7 @@ static int launch_decide(monsoon_t* h, int n, int max_turns, int write_scores, b
       hipDeviceProp_t prop;                                                                                             \
       HIP_TRY(h, hipGetDeviceProperties(&prop, h->device));                                                             \
       HIP_TRY(h, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_decide<U, W>, 64, DecideLds<U>::TOTAL + lds_pad)); \
-      h->grid_waves = per_cu > 0 ? per_cu * prop.multiProcessorCount : 4096;                                            \
+      h->grid_waves = 2 * (per_cu > 0 ? per_cu * prop.multiProcessorCount : 4096);   /* two waves per slot: measured best */                                            \
       if (const char* e = getenv("MONSOON_GRID")) h->grid_waves = atoi(e);                                              \
     }                                                                                                                   \
     int grid = (persistent && h->grid_waves < n) ? h->grid_waves : n;                                                   \
@@ -1206,12 +1245,44 @@ int monsoon_rollout(monsoon_t* h, const double* weights, int32_t n_individuals, 
   return MONSOON_OK;
 }
 
+// current statistics of the loaded games (see k_stats)
+static int reduce_stats(monsoon_t* h, unsigned long long cur[5]) {
+  for (int i = 0; i < 5; i++) cur[i] = 0;
+  if (h->n <= 0) return MONSOON_OK;
+  HIP_TRY(h, hipMemsetAsync(h->b.stats, 0, 5 * sizeof(unsigned long long), h->stream));
+  int blocks = (h->n + 255) / 256;
+  if (blocks > 256) blocks = 256;
+  hipLaunchKernelGGL(k_stats, dim3(blocks), dim3(256), 0, h->stream, h->b, h->n, h->b.stats);
+  HIP_TRY(h, hipGetLastError());
+  HIP_TRY(h, hipMemcpyAsync(cur, h->b.stats, 5 * sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  return MONSOON_OK;
+}
+static int total_stats(monsoon_t* h, unsigned long long tot[5]) {
+  unsigned long long cur[5];
+  int rc = reduce_stats(h, cur);
+  if (rc) return rc;
+  for (int i = 0; i < 5; i++) tot[i] = h->st_acc[i] + cur[i] - h->st_base[i];
+  return MONSOON_OK;
+}
+// the loaded games are about to be replaced: keep what they contributed
+static int fold_stats(monsoon_t* h) {
+  unsigned long long tot[5];
+  int rc = total_stats(h, tot);
+  if (rc) return rc;
+  for (int i = 0; i < 5; i++) {
+    h->st_acc[i] = tot[i];
+    h->st_base[i] = 0;
+  }
+  return MONSOON_OK;
+}
+
 int monsoon_get_stats(monsoon_t* h, monsoon_stats* out) {
   if (!h || !out) return MONSOON_ERR_ARG;
   HIP_TRY(h, hipSetDevice(h->device));
-  unsigned long long s[8];
-  HIP_TRY(h, hipStreamSynchronize(h->stream));
-  HIP_TRY(h, hipMemcpy(s, h->b.stats, sizeof(s), hipMemcpyDeviceToHost));
+  unsigned long long s[5];
+  int rc = total_stats(h, s);
+  if (rc) return rc;
   out->lookahead_steps = s[ST_LOOKAHEAD];
   out->decisions = s[ST_DECISIONS];
   out->games_finished = s[ST_FINISHED];
@@ -1225,7 +1296,10 @@ int monsoon_debug_counters(monsoon_t* h, unsigned long long* out) {
   if (!h || !out) return MONSOON_ERR_ARG;
   HIP_TRY(h, hipStreamSynchronize(h->stream));
   memset(out, 0, 192 * sizeof(unsigned long long));
-  HIP_TRY(h, hipMemcpy(out, h->b.stats, ST_WORDS * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+  {
+    int rc = total_stats(h, out);
+    if (rc) return rc;
+  }
 #if defined(MSB_PROF) && MSB_PROF
   {
     std::vector<unsigned long long> v((size_t)h->cfg.max_games * PROF_WORDS);
@@ -1275,7 +1349,15 @@ int monsoon_reset_stats(monsoon_t* h) {
   HIP_TRY(h, hipSetDevice(h->device));
   HIP_TRY(h, hipStreamSynchronize(h->stream));
   drain_timing(h);
-  HIP_TRY(h, hipMemset(h->b.stats, 0, ST_WORDS * sizeof(unsigned long long)));
+  {
+    unsigned long long cur[5];
+    int rc = reduce_stats(h, cur);
+    if (rc) return rc;
+    for (int i = 0; i < 5; i++) {
+      h->st_acc[i] = 0;
+      h->st_base[i] = cur[i];
+    }
+  }
   if (h->b.prof) HIP_TRY(h, hipMemset(h->b.prof, 0, (size_t)h->cfg.max_games * PROF_WORDS * sizeof(unsigned long long)));
   h->kernel_ms = 0;
   h->kernel_launches = 0;

@@ -119,6 +119,28 @@ enum : int { SH_FRONT, SH_BEHIND, SH_SIDE, SH_ROW, SH_COLUMN, SH_BORDERING, SH_S
 
 constexpr int MAX_DEPTH = 40;
 
+// Which rules-core functions are inlined into their callers was settled by same-box A/B runs (scripts/ab_env.sh)
+// measured (same-box A/B, 65 536 games): new_entity + set_path + calculate_front_line inlined +2.4 %;
+// entity_deal_damage inlined +0.6 %; player_play inlined -15 %
+#define MSB_A_NEWENT MSB_INL
+#define MSB_A_SETPATH MSB_INL
+#define MSB_A_FRONT MSB_INL
+#define MSB_A_PLAY MSB_NOINLINE
+// second batch: get_targets inlined +7.8 %, shape_targets +5 %, entity_deal_damage +1.6 %, draw +1.2 %, destroy -3 %
+#define MSB_A_DAMAGE MSB_INL
+#define MSB_A_TARGETS MSB_INL
+#define MSB_A_DRAW MSB_INL
+#define MSB_A_DESTROY MSB_NOINLINE
+#define MSB_A_SHAPE MSB_INL
+// third batch (no gain, left out-of-line): shape_tiles +0.4 %, shuffle/sorted_head 0, legal_mask_v +0.2 %,
+// command/teleport/push_pull/force_attack/spawn/respawn +0.8 %; flip + to_next_turn inlined -8.5 %, ability_spell -18 %.
+// One non-inlined function per card instead of one switch function (abilities.inc): +3 %.
+#define MSB_A_TILES MSB_NOINLINE
+#define MSB_A_SHUFFLE MSB_NOINLINE
+#define MSB_A_LEGAL MSB_NOINLINE
+#define MSB_A_MISC MSB_NOINLINE
+#define MSB_A_TURN MSB_NOINLINE
+
 template <class M>
 struct Engine {
   M m;
@@ -471,7 +493,7 @@ struct Engine {
     MSB_POSTCALL(PS_NEW_ENTITY);
     return r_;
   }
-  MSB_HD MSB_NOINLINE int new_entity_impl(int card, int owner, int strength, int movement, bool ff) {
+  MSB_HD MSB_A_NEWENT int new_entity_impl(int card, int owner, int strength, int movement, bool ff) {
     MSB_SCOPE(PS_NEW_ENTITY);
     int e = alloc_entity();
     if (fault()) return e;
@@ -570,7 +592,7 @@ struct Engine {
 
   // Board.calculate_front_line, board.py:78-92.  `player` is an order; the reference compares
   // Player objects by order (player.py:39-40).
-  MSB_HD MSB_NOINLINE void calculate_front_line(int player) {
+  MSB_HD MSB_A_FRONT void calculate_front_line(int player) {
     MSB_SCOPE(PS_FRONT_LINE);
     // any(board[y][x] is not None and board[y][x].player == player for x in range(4)) per row: the first
     // (local: lowest y, remote: highest y) row holding one of the player's entities; only occupied tiles are read
@@ -608,7 +630,7 @@ struct Engine {
     MSB_POSTCALL(PS_GET_TARGETS);
     return r_;
   }
-  MSB_HD MSB_NOINLINE PList get_targets_impl(int pov, Tgt t, int exclude_pk) {
+  MSB_HD MSB_A_TARGETS PList get_targets_impl(int pov, Tgt t, int exclude_pk) {
     MSB_SCOPE(PS_GET_TARGETS);
     PList out;
     out.clear();
@@ -701,7 +723,7 @@ struct Engine {
     }
   }
   // get_front_tiles .. get_surrounding_tiles WITHOUT a target: fixed enumeration order.
-  MSB_HD MSB_NOINLINE PList shape_tiles(int shape, P c, int pov) {
+  MSB_HD MSB_A_TILES PList shape_tiles(int shape, P c, int pov) {
     MSB_SCOPE(PS_SHAPE_TILES);
     PList out;
     out.clear();
@@ -755,7 +777,7 @@ struct Engine {
     return out;
   }
   // ... WITH a target: get_targets order filtered by membership; front/behind re-sorted by y.
-  MSB_HD MSB_NOINLINE PList shape_targets(int shape, P c, int pov, Tgt t, int exclude_pk) {
+  MSB_HD MSB_A_SHAPE PList shape_targets(int shape, P c, int pov, Tgt t, int exclude_pk) {
     MSB_SCOPE(PS_SHAPE_TARGETS);
     PList all = get_targets(pov, t, exclude_pk);
     PList out;
@@ -788,7 +810,7 @@ struct Engine {
   // numpy RandomState.choice(list) / shuffle(list)
   MSB_HD MSB_INL int choice_index(int n) { return rng_randint(0, n); }
   MSB_HD MSB_INL P choice_point(PList l) { return l.at(choice_index(l.n())); }
-  MSB_HD MSB_NOINLINE PList shuffle(PList l) {
+  MSB_HD MSB_A_SHUFFLE PList shuffle(PList l) {
     MSB_SCOPE(PS_SHUFFLE);
     for (int i = l.n() - 1; i >= 1; i--) {
       int j = (int)rng_interval((uint32_t)i);
@@ -802,7 +824,7 @@ struct Engine {
   // cards make of it (b002 b008 b009 b104 s101).  random() is called once per element in list order
   // BEFORE sorting; the sort is stable and reverse keeps ties in order, so the first k of the sorted
   // list are the k best under (key, r) with earlier elements winning ties.  key_mode: 0 = y, 1 = strength.
-  MSB_HD MSB_NOINLINE PList sorted_head(PList l, int key_mode, bool rev, int k) {
+  MSB_HD MSB_A_SHUFFLE PList sorted_head(PList l, int key_mode, bool rev, int k) {
     MSB_SCOPE(PS_SORTED_HEAD);
     int b0 = -1, b1 = -1, k0 = 0, k1 = 0;
     double r0 = 0.0, r1 = 0.0;
@@ -909,7 +931,7 @@ struct Engine {
     MSB_POSTCALL(PS_DEAL_DAMAGE);
     return r_;
   }
-  MSB_HD MSB_NOINLINE int entity_deal_damage_impl(int e, int amount, bool pending, bool src) {
+  MSB_HD MSB_A_DAMAGE int entity_deal_damage_impl(int e, int amount, bool pending, bool src) {
     MSB_SCOPE(PS_DEAL_DAMAGE);
     int s = e_str(e);
     if (s - amount < 0) amount = s;
@@ -948,7 +970,7 @@ struct Engine {
     MSB_POSTCALL(PS_DESTROY);
     
   }
-  MSB_HD MSB_NOINLINE void destroy_impl(int e, bool src) {
+  MSB_HD MSB_A_DESTROY void destroy_impl(int e, bool src) {
     MSB_SCOPE(PS_DESTROY);
     if (e_is_unit(e)) {
       board_set(e_pos(e), -1);
@@ -1007,7 +1029,7 @@ struct Engine {
     MSB_POSTCALL(PS_SET_PATH);
     
   }
-  MSB_HD MSB_NOINLINE void set_path_impl(int e, bool on_play) {
+  MSB_HD MSB_A_SETPATH void set_path_impl(int e, bool on_play) {
     MSB_SCOPE(PS_SET_PATH);
     P position = e_pos(e);
     int confused_cached = e_st(e, ST_CONFUSED);
@@ -1186,7 +1208,7 @@ struct Engine {
     m.st8(ent(e) + EO_MOV, mv);
   }
   // Unit.command, unit.py:282-289
-  MSB_HD MSB_NOINLINE void command(int e) {
+  MSB_HD MSB_A_MISC void command(int e) {
     MSB_SCOPE(PS_COMMAND);
     if (!need_unit(e)) return;
     bool ff = e_ff(e);
@@ -1203,7 +1225,7 @@ struct Engine {
     set_path(e, e_resolving_play(e));
   }
   // Unit.teleport, unit.py:373-382
-  MSB_HD MSB_NOINLINE void teleport(int e, P dest) {
+  MSB_HD MSB_A_MISC void teleport(int e, P dest) {
     MSB_SCOPE(PS_TELEPORT);
     if (at(dest) == AT_NONE) {
       board_set(e_pos(e), -1);
@@ -1214,7 +1236,7 @@ struct Engine {
     }
   }
   // Unit.push (away from `from`) unit.py:318-339 and Unit.pull (towards) unit.py:295-316
-  MSB_HD MSB_NOINLINE void push_pull(int e, P from, bool is_push) {
+  MSB_HD MSB_A_MISC void push_pull(int e, P from, bool is_push) {
     MSB_SCOPE(PS_PUSH_PULL);
     if (!need_unit(e)) return;
     P pos = e_pos(e);
@@ -1241,7 +1263,7 @@ struct Engine {
     if (pl_front(o) > y) set_pl_front(o, y > 1 ? y : 1);
   }
   // Unit.force_attack, unit.py:341-371
-  MSB_HD MSB_NOINLINE void force_attack(int e, P dest) {
+  MSB_HD MSB_A_MISC void force_attack(int e, P dest) {
     MSB_SCOPE(PS_FORCE_ATTACK);
     P pos = e_pos(e);
     if ((dest.x != pos.x && dest.y != pos.y) || at(dest) == AT_NONE) return;
@@ -1269,7 +1291,7 @@ struct Engine {
     }
   }
   // Board.spawn_token_unit, board.py:298-311 (types always given by the cards)
-  MSB_HD MSB_NOINLINE int spawn_token_unit(int owner, P position, int strength, int unit_type) {
+  MSB_HD MSB_A_MISC int spawn_token_unit(int owner, P position, int strength, int unit_type) {
     MSB_SCOPE(PS_SPAWN);
     int e = new_entity(TOKEN_UNIT_BASE + unit_type, owner, strength, 1, false);
     if (fault()) return e;
@@ -1279,7 +1301,7 @@ struct Engine {
   }
   // Unit.respawn unit.py:384-402 / Structure.respawn structure.py:77-89: a fresh object of the same
   // class with the given strength is written onto the tile (whatever was there is overwritten).
-  MSB_HD MSB_NOINLINE void respawn(int e, P position, int strength) {
+  MSB_HD MSB_A_MISC void respawn(int e, P position, int strength) {
     MSB_SCOPE(PS_RESPAWN);
     int c = e_card(e);
     int ne;
@@ -1318,7 +1340,7 @@ struct Engine {
   }
 
   // Player.draw, player.py:46-52: numpy choice(deck, size=1, p=w/sum(w))
-  MSB_HD MSB_NOINLINE void draw(int o, int amount) {
+  MSB_HD MSB_A_DRAW void draw(int o, int amount) {
     MSB_SCOPE(PS_DRAW);
     for (int k = 0; k < amount; k++) {
       int n = pl_deck_n(o);
@@ -1394,7 +1416,7 @@ struct Engine {
     MSB_POSTCALL(PS_PLAYER_PLAY);
     
   }
-  MSB_HD MSB_NOINLINE void player_play_impl(int o, int index, P position, bool has_pos) {
+  MSB_HD MSB_A_PLAY void player_play_impl(int o, int index, P position, bool has_pos) {
     MSB_SCOPE(PS_PLAYER_PLAY);
     int card = hand_card(o, index), fl = hand_flags(o, index);
     int strength = inst_strength(card, fl, hand_x(o, index));   // target.copy() copies the instance's strength
@@ -1447,7 +1469,7 @@ struct Engine {
   // ------------------------------------------------------------------------------------------
   // Board.flip, board.py:94-115.  H_TOPLAY has already been toggled by the caller, which swaps
   // local/remote; entity.player keeps the same PlayerOrder through the "ownership swap".
-  MSB_HD MSB_NOINLINE void flip() {
+  MSB_HD MSB_A_TURN void flip() {
     MSB_SCOPE(PS_FLIP);
     set_pl_front(0, 4 - pl_front(0));
     set_pl_front(1, 4 - pl_front(1));
@@ -1464,7 +1486,7 @@ struct Engine {
     }
   }
   // Board.to_next_turn, board.py:117-145
-  MSB_HD MSB_NOINLINE void to_next_turn() {
+  MSB_HD MSB_A_TURN void to_next_turn() {
     MSB_SCOPE(PS_NEXT_TURN);
     m.st8(H_PHASE, PH_TURN_END);
     int ender = cp();
@@ -1508,7 +1530,7 @@ struct Engine {
 
   // Stormbound.legal_actions + Action.to_int, games/stormbound.py:528-557, 258-290 -> 156-bit mask
   // (three 64-bit words in a register vector)
-  MSB_HD MSB_NOINLINE msb_u64x4 legal_mask_v() {
+  MSB_HD MSB_A_LEGAL msb_u64x4 legal_mask_v() {
     MSB_SCOPE(PS_LEGAL);
     unsigned long long m0 = 0, m1 = 0, m2 = 0;
     int lo = local();
