@@ -97,6 +97,11 @@ int monsoon_features(monsoon_t* h, double* out);
  * {to_play, have_winner, base_first, base_second}. */
 int monsoon_status(monsoon_t* h, int32_t* out);
 
+/* The fault code that stopped each loaded game (0 = none): out[n].  The reference's exceptions are swallowed by
+ * its agent layer (evo/heuristic_agent.py:48-51, evo/fitness.py:170-174,208-210); codes in msb_base.h, >= 16 are
+ * limits of this build. */
+int monsoon_game_faults(monsoon_t* h, uint8_t* out);
+
 /* Canonical state record of game idx (layout: monsoon_amd/csrc/canon.h), the comparand of the
  * bit-exactness tests.  buf must hold 1024 bytes. */
 int monsoon_state_export(monsoon_t* h, int32_t idx, uint8_t* buf, int32_t* len);

@@ -50,6 +50,7 @@ SIGNATURES = {
     "monsoon_step": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
     "monsoon_expert_action": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
     "monsoon_observe": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
+    "monsoon_game_faults": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p]),
     "monsoon_observe_dev": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
     "monsoon_features": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p]),
     "monsoon_status": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p]),

@@ -616,6 +616,11 @@ __global__ void __launch_bounds__(256) k_stats(DevBuffers b, int n, unsigned lon
   }
 }
 
+__global__ void k_faults(DevBuffers b, int n, uint8_t* out) {
+  int g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g < n) out[g] = b.meta[g].fault;
+}
+
 __global__ void k_clear_scores(double* scores, size_t n) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) scores[i] = NAN;
@@ -1007,6 +1012,18 @@ int monsoon_debug_raw(monsoon_t* h, int32_t idx, uint8_t* buf, int32_t* len) {
   HIP_TRY(h, hipStreamSynchronize(h->stream));
   HIP_TRY(h, hipMemcpy(buf, h->b.state + (size_t)idx * SW, STATE_BYTES, hipMemcpyDeviceToHost));
   *len = STATE_BYTES;
+  return MONSOON_OK;
+}
+
+int monsoon_game_faults(monsoon_t* h, uint8_t* out) {
+  int rc = check_ready(h);
+  if (rc) return rc;
+  if (!out) return MONSOON_ERR_ARG;
+  int n = h->n;
+  hipLaunchKernelGGL(k_faults, dim3((n + 255) / 256), dim3(256), 0, h->stream, h->b, n, h->d_bytes);
+  HIP_TRY(h, hipGetLastError());
+  HIP_TRY(h, hipMemcpyAsync(out, h->d_bytes, (size_t)n, hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
   return MONSOON_OK;
 }
 

@@ -89,6 +89,12 @@ class BatchEngine:
         self._ck(self.lib.monsoon_observe(self.h, _ptr(out), _ptr(raises)), "monsoon_observe")
         return out, raises
 
+    def game_faults(self):
+        """Per-game fault code of the loaded batch (0 = none)."""
+        out = np.zeros(self.n, dtype=np.uint8)
+        self._ck(self.lib.monsoon_game_faults(self.h, _ptr(out)), "monsoon_game_faults")
+        return out
+
     def observe_torch(self):
         """(n,27,5,4) int32 observation as a torch tensor ON THE GPU (no host copy), plus the raises mask.
         torch is used for device memory only."""

@@ -33,23 +33,37 @@ def hash32(*vals):
     return h
 
 
+def hash32_array(*vals):
+    """hash32 over broadcastable integer arrays (same values as the scalar form, element by element)."""
+    M = np.uint64(0xFFFFFFFF)
+    vals = np.broadcast_arrays(*[np.asarray(v, dtype=np.uint64) for v in vals])
+    h = np.full(vals[0].shape, 0x9E3779B9, dtype=np.uint64)
+    for v in vals:
+        h = h ^ ((v + np.uint64(0x7F4A7C15) + ((h << np.uint64(6)) & M) + (h >> np.uint64(2))) & M)
+        h = (h * np.uint64(0x85EBCA6B)) & M
+        h = h ^ (h >> np.uint64(13))
+        h = (h * np.uint64(0xC2B2AE35)) & M
+        h = h ^ (h >> np.uint64(16))
+    return h.astype(np.uint32)
+
+
 def round_robin_schedule(n_individuals, n_total_opponents, games_per_pairing, generation):
     """evo/fitness.py:53-59,133: every individual vs every other opponent (population + hall of fame)."""
-    rows = []
-    for i in range(n_individuals):
-        for j in range(n_total_opponents):
-            if j < n_individuals and i == j:
-                continue
-            for g in range(games_per_pairing):
-                rows.append((i, j, hash32(generation, i, j, g), 0))
-    return np.array(rows, dtype=MATCH_DTYPE)
+    i, j, g = np.meshgrid(np.arange(n_individuals), np.arange(n_total_opponents), np.arange(games_per_pairing), indexing="ij")
+    keep = (i != j).ravel()   # j < n_individuals and i == j is skipped; a hall-of-fame j is never < n_individuals when equal
+    i, j, g = i.ravel()[keep], j.ravel()[keep], g.ravel()[keep]
+    out = np.zeros(len(i), dtype=MATCH_DTYPE)
+    out["p1"], out["p2"], out["seed"] = i, j, hash32_array(generation, i, j, g)
+    return out
 
 
 def ring_schedule(n_individuals, games_per_individual, generation):
     """individual i plays FIRST against (i+1+k) mod N, k = 0..games-1."""
-    rows = [(i, (i + 1 + k) % n_individuals, hash32(generation, i, k), 0)
-            for i in range(n_individuals) for k in range(games_per_individual)]
-    return np.array(rows, dtype=MATCH_DTYPE)
+    i, k = np.meshgrid(np.arange(n_individuals), np.arange(games_per_individual), indexing="ij")
+    i, k = i.ravel(), k.ravel()
+    out = np.zeros(len(i), dtype=MATCH_DTYPE)
+    out["p1"], out["p2"], out["seed"] = i, (i + 1 + k) % n_individuals, hash32_array(generation, i, k)
+    return out
 
 
 def shard_by_individual(matches, n_individuals, rank, world):
@@ -68,7 +82,7 @@ def fitness_from_counts(counts, games_per_individual):
 class FitnessEvaluator:
     def __init__(self, config, deck_config=None, rollout_fn=None, device=None):
         self.config = config
-        self.deck_config = deck_config      # accepted for signature parity; decks come from config.deck
+        self.deck_config = deck_config      # monsoon_amd.decks.DeckEvolutionConfig (utils.py:121-242) or None = config.deck both sides
         self.total_games = 0
         self.total_time = 0.0
         self.total_env_steps = 0
@@ -77,21 +91,43 @@ class FitnessEvaluator:
         self.use_hall_of_fame = True
         self._rollout_fn = rollout_fn
         self._device = device
-        self._engine = None
+        self._engines = {}
 
     # -- device ------------------------------------------------------------------------------
     def _hip_rollout(self, weights, matches, deck_pairs, max_turns):
+        from .cards import needs_extended
         from .engine import BatchEngine
-        if self._engine is None:
+        ext = bool(needs_extended(deck_pairs))   # ua20 / b005 only run on the extended-record build
+        if self._engines.get(ext) is None:
             dev = self._device
             if dev is None:
                 import os
                 dev = int(os.environ.get("LOCAL_RANK", "0"))
-            self._engine = BatchEngine(self.config.max_concurrent_games, device=dev, lanes_per_game=self.config.lanes_per_game)
-        before = self._engine.stats()["lookahead_steps"]
-        counts = self._engine.rollout(weights, matches, deck_pairs, max_turns)
-        self.total_env_steps += self._engine.stats()["lookahead_steps"] - before
+            self._engines[ext] = BatchEngine(self.config.max_concurrent_games, device=dev, lanes_per_game=self.config.lanes_per_game,
+                                             extended=ext)
+        eng = self._engines[ext]
+        before = eng.stats()["lookahead_steps"]
+        counts = eng.rollout(weights, matches, deck_pairs, max_turns)
+        self.total_env_steps += eng.stats()["lookahead_steps"] - before
         return counts
+
+    def _decks_for(self, matches, generation):
+        """Deck pairs [n_decks][2][12] for a schedule; fills matches["deck"].  Without a deck_config: config.deck both
+        sides.  With one: utils.py:155-219 per GAME, as games/evolutionary_stormbound.py:52 draws them (one pair for
+        the whole generation while the schedule is in its exploit phase)."""
+        from .cards import deck_indices
+        if self.deck_config is None:
+            deck = deck_indices(self.config.deck)
+            return np.stack([deck, deck])[None]
+        if self.deck_config.is_static(generation):
+            d1, d2 = self.deck_config.get_deck_configuration(generation)
+            return np.stack([deck_indices(d1), deck_indices(d2)])[None]
+        pairs = np.zeros((len(matches), 2, 12), dtype=np.uint8)
+        for k in range(len(matches)):
+            d1, d2 = self.deck_config.get_deck_configuration(generation)
+            pairs[k, 0], pairs[k, 1] = deck_indices(d1), deck_indices(d2)
+        matches["deck"] = np.arange(len(matches))
+        return pairs
 
     @staticmethod
     def _dist():
@@ -126,12 +162,15 @@ class FitnessEvaluator:
             np.add.at(counts[:, 2], matches["p1"], 1)
         else:
             weights = np.stack([np.asarray(o.weights, dtype=np.float64) for o in opponents])
-            deck = deck_indices(cfg.deck)
-            deck_pairs = np.stack([deck, deck])[None]
+            deck_pairs = self._decks_for(matches, generation)   # drawn for the WHOLE schedule, so every rank sees the same decks
             dist = self._dist()
             mine = matches
             if dist is not None:
                 mine = shard_by_individual(matches, n, dist.get_rank(), dist.get_world_size())
+                if len(deck_pairs) > 1 and len(mine):   # keep only this rank's decks
+                    deck_pairs = deck_pairs[mine["deck"]]
+                    mine = mine.copy()
+                    mine["deck"] = np.arange(len(mine))
             fn = self._rollout_fn or self._hip_rollout
             counts = np.zeros((n_total, 3), dtype=np.int64)
             if len(mine):

@@ -304,6 +304,42 @@ def gen_population():
                         off_weights=np.array([i.get_weights() for i in off]), off_sigmas=np.array([i.get_sigmas() for i in off]))
 
 
+def gen_decks():
+    """utils.generate_random_deck / DeckEvolutionConfig of the reference, Python's global `random` seeded per case."""
+    import json
+    import random
+    import utils as RU
+    from enums import Faction
+    cls = {c: getattr(H.refcards, c.upper()) for c in H.CARD_IDS}
+
+    def ids(deck):
+        return [type(c).__name__.lower() for c in deck]
+
+    cases = []
+    arche = {"IRONCLAD": H.DECKS["IRONCLAD"], "SWARM": H.DECKS["SWARM"], "N12M": H.DECKS["N12M"]}
+    k = 0
+    for fac in (0, 1, 2, 3, 4):
+        for name, deck in arche.items():
+            for ratio in (0.0, 0.25, 0.5, 0.9, 1.0):
+                k += 1
+                random.seed(1000 + k)
+                out = RU.generate_random_deck(Faction(fac), original=[cls[c]() for c in deck], preserve_ratio=ratio)
+                cases.append({"seed": 1000 + k, "faction": fac, "original": list(deck), "ratio": ratio, "deck": ids(out)})
+    sched = []
+    for seed in (7, 8):
+        cfg = RU.DeckEvolutionConfig([cls[c]() for c in H.DECKS["IRONCLAD"]], [cls[c]() for c in H.DECKS["SWARM"]],
+                                     exploit_generations=2, explore_generations=4, max_random_ratio=0.5, balance_archetype_ratio=0.7)
+        random.seed(seed)
+        rows = []
+        for gen in range(10):
+            for _ in range(3):
+                d1, d2 = cfg.get_deck_configuration(gen)
+                rows.append({"generation": gen, "p1": ids(d1), "p2": ids(d2)})
+        sched.append({"seed": seed, "rows": rows, "phase": [cfg.get_phase_info(g) for g in range(10)]})
+    with open(os.path.join(GOLD, "deck_schedule.json"), "w") as f:
+        json.dump({"generate_random_deck": cases, "schedule": sched}, f, indent=0)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default=None)
@@ -323,6 +359,7 @@ def main():
         "random_S12": lambda: gen_random("S12", None, 48, 300, args.jobs),
         "expert": lambda: gen_expert(48, 300, args.jobs),
         "heuristic": lambda: gen_heuristic(12, 200, args.jobs),
+        "decks": gen_decks,
     }
     for name, fn in todo.items():
         if args.only and args.only != name:

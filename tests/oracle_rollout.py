@@ -9,7 +9,8 @@ def oracle_rollout_fn(weights, matches, deck_pairs, max_turns, want_results=Fals
     weights = np.ascontiguousarray(weights, dtype=np.float64)
     deck_pairs = np.asarray(deck_pairs, dtype=np.uint8).reshape(-1, 2, 12)
     counts = np.zeros((len(weights), 3), dtype=np.int64)
-    orc = oracle_lib.Oracle(1)
+    from monsoon_amd.cards import needs_extended
+    orc = oracle_lib.Oracle(1, extended=bool(needs_extended(deck_pairs)))   # ua20 / b005: extended record, like the product
     results = np.zeros(len(matches), dtype=np.int8)
     steps = np.zeros(len(matches), dtype=np.int32)
     for k, m in enumerate(matches):

@@ -179,6 +179,26 @@ def test_rollout_schedule_two_weight_vectors(engines):
     assert np.array_equal(counts, ocounts)
 
 
+def test_fitness_with_deck_schedule_equals_cpu_replay():
+    """Seam F with a DeckEvolutionConfig in its explore phase (a deck pair per game): fitness from the HIP rollout
+    equals the fitness from the CPU replay of the same schedule."""
+    from oracle_rollout import oracle_rollout_fn
+    from monsoon_amd.cards import DECKS
+    from monsoon_amd.config import EvolutionaryConfig
+    from monsoon_amd.decks import DeckEvolutionConfig
+    from monsoon_amd.fitness import FitnessEvaluator
+    from monsoon_amd.weights import WeightVector
+    np.random.seed(4)
+    pop = [WeightVector(10) for _ in range(4)]
+    cfg = EvolutionaryConfig(mu=4, lambda_=4, games_per_pairing=2, max_turns=60, max_concurrent_games=64)
+    out = []
+    for fn in (None, oracle_rollout_fn):
+        dc = DeckEvolutionConfig(DECKS["IRONCLAD"], DECKS["SWARM"], exploit_generations=1, explore_generations=4, seed=5)
+        ev = FitnessEvaluator(cfg, dc, rollout_fn=fn)
+        out.append((ev.evaluate_population(pop, 0), ev.evaluate_population(pop, 3)))
+    assert out[0] == out[1]
+
+
 def test_full_size_65536_games_bit_exact_and_deterministic(engines):
     """BASELINE configs[1]: 65 536 concurrent N12M self-play games, 200 decision rounds; every
     final canonical record and per-game decision count equals the CPU replay; a second run of the

@@ -103,3 +103,64 @@ def test_evolution_engine_end_to_end(tmp_path):
     eng2 = EvolutionEngine(cfg, rollout_fn=oracle_rollout_fn)
     eng2.load_checkpoint(res["final_population_file"])
     assert eng2.population.generation == 2
+
+
+def test_vectorised_schedules_equal_the_scalar_definition():
+    """hash32_array / the numpy schedules give exactly the rows of the per-match Python loops they replace."""
+    from monsoon_amd.fitness import MATCH_DTYPE, hash32, hash32_array, ring_schedule, round_robin_schedule
+    assert [int(x) for x in hash32_array(7, np.arange(5), 3)] == [hash32(7, i, 3) for i in range(5)]
+    ref = np.array([(i, (i + 1 + k) % 16, hash32(3, i, k), 0) for i in range(16) for k in range(8)], dtype=MATCH_DTYPE)
+    assert (ring_schedule(16, 8, 3) == ref).all()
+    rows = [(i, j, hash32(5, i, j, g), 0) for i in range(6) for j in range(9) if not (j < 6 and i == j) for g in range(2)]
+    assert (round_robin_schedule(6, 9, 2, 5) == np.array(rows, dtype=MATCH_DTYPE)).all()
+
+
+def test_deck_schedule_equals_the_reference_draws():
+    """monsoon_amd.decks vs utils.generate_random_deck / DeckEvolutionConfig of the reference run with the same
+    `random` seed (tests/golden/deck_schedule.json, oracle/pyref/gen_golden.py --only decks)."""
+    import json
+    import random
+    from monsoon_amd.cards import DECKS
+    from monsoon_amd.decks import DeckEvolutionConfig, generate_random_deck
+    g = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "deck_schedule.json")))
+    assert len(g["generate_random_deck"]) == 75
+    for c in g["generate_random_deck"]:
+        assert generate_random_deck(c["faction"], c["original"], c["ratio"], random.Random(c["seed"])) == c["deck"]
+    for s in g["schedule"]:
+        cfg = DeckEvolutionConfig(DECKS["IRONCLAD"], DECKS["SWARM"], 2, 4, 0.5, 0.7, seed=s["seed"])
+        rows = iter(s["rows"])
+        for gen in range(10):
+            for _ in range(3):
+                r = next(rows)
+                assert cfg.get_deck_configuration(gen) == (r["p1"], r["p2"])
+        assert [cfg.get_phase_info(k) for k in range(10)] == s["phase"]
+
+
+def test_evaluator_draws_a_deck_pair_per_game_from_the_schedule():
+    """Seam F with a deck schedule: one pair for the whole generation while exploiting, a fresh draw per game
+    afterwards (games/evolutionary_stormbound.py:52); decks reach the rollout as index arrays."""
+    from monsoon_amd.cards import DECKS, deck_indices
+    from monsoon_amd.decks import DeckEvolutionConfig
+    seen = []
+
+    def fake(weights, matches, deck_pairs, max_turns):
+        seen.append((np.array(matches["deck"]), np.array(deck_pairs)))
+        c = np.zeros((len(weights), 3), dtype=np.int64)
+        np.add.at(c[:, 2], matches["p1"], 1)
+        return c
+
+    np.random.seed(3)
+    cfg = EvolutionaryConfig(mu=3, lambda_=3, games_per_pairing=2, max_turns=5)
+    pop = [WeightVector(10) for _ in range(3)]
+    for trial in range(2):
+        dc = DeckEvolutionConfig(DECKS["IRONCLAD"], DECKS["SWARM"], exploit_generations=1, explore_generations=2, seed=11)
+        ev = FitnessEvaluator(cfg, dc, rollout_fn=fake)
+        ev.use_hall_of_fame = False
+        ev.evaluate_population(pop, 0)
+        ev.evaluate_population(pop, 2)
+    (d0, p0), (d2, p2) = seen[0], seen[1]
+    assert p0.shape == (1, 2, 12) and (d0 == 0).all()
+    assert np.array_equal(p0[0, 0], deck_indices("IRONCLAD")) and np.array_equal(p0[0, 1], deck_indices("SWARM"))
+    assert p2.shape == (12, 2, 12) and np.array_equal(d2, np.arange(12))
+    assert len({p2[k].tobytes() for k in range(12)}) > 1            # explore phase: the games differ
+    assert np.array_equal(seen[3][1], p2)                          # same seed, same schedule
