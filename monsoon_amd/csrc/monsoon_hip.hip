@@ -49,6 +49,7 @@ struct GameMeta {
   uint8_t fault;
   uint8_t last_action;
   uint8_t flags;           // b0: ended with a winner (have_winner), as opposed to max_turns / a fault
+                           // b1: cfeat[last_action] holds the features of the CURRENT state (it was the committed successor)
   uint16_t steps;          // committed steps (decisions and monsoon_step calls)
   uint16_t decided;        // decisions committed by k_decide
   uint32_t rng;            // cursor (bits 0-15) | current block (bit 16)
@@ -65,6 +66,7 @@ struct DevBuffers {
   unsigned long long* stats;  // [8]: lookahead, decisions, finished, faults, capacity_faults
   double* scores;      // [cap][156] or null
   double* best;        // [cap]
+  double* cfeat;       // [cap][156][10] features of every look-ahead successor of the last decision, by action id
   int* pop;            // [2][POP_PARTS * POP_STRIDE] game-index counters of the persistent k_decide, alternating between launches
   unsigned long long* prof;   // [cap][..] phase cycles, scope cycles, scope calls (profiling build), profiling build only (else null)
 };
@@ -295,6 +297,7 @@ __global__ void __launch_bounds__(64) k_step(DevBuffers b, int n, const uint8_t*
   lane_commit_rng(b, g, m, e.rng_pos());
   m.steps++;
   m.last_action = (uint8_t)a;
+  m.flags &= ~2;   // no cached features for a state reached through monsoon_step
   if (e.fault()) m.fault = (uint8_t)e.fault();
   b.meta[g] = m;
   api_store(b.state + (size_t)g * SW);
@@ -441,12 +444,20 @@ __device__ void decide_game(const DevBuffers& b, const int g, const int lane, in
   // weights and "before" features are parked in LDS: 40 fewer live VGPRs across the recursive step calls
   MSB_AS_LDS double* wf = (MSB_AS_LDS double*)(uintptr_t)L::WF;
   {
-    double fb[10];
-    if (!before_raises) pe.features(fb);
     const double* wt = b.weights + (size_t)(pe.local() == 0 ? meta.p1 : meta.p2) * 10;
     if (lane < 10) wf[lane] = wt[lane];
-    if (lane == 0 && !before_raises)
-      for (int i = 0; i < 10; i++) wf[10 + i] = fb[i];
+    // The "before" features of this decision are the "after" features the previous decision computed for the
+    // successor it committed (same state, same mover): they were kept by action id.
+    if (!before_raises) {
+      if ((meta.flags & 2) && meta.last_action < MONSOON_NUM_ACTIONS) {
+        if (lane < 10) wf[10 + lane] = b.cfeat[((size_t)g * MONSOON_NUM_ACTIONS + meta.last_action) * 10 + lane];
+      } else {
+        double fb[10];
+        pe.features(fb);
+        if (lane == 0)
+          for (int i = 0; i < 10; i++) wf[10 + i] = fb[i];
+      }
+    }
   }
   __syncthreads();
   PROF_MARK(2);   // before-features
@@ -459,6 +470,7 @@ __device__ void decide_game(const DevBuffers& b, const int g, const int lane, in
   int run_a = NONE_A;
   uint32_t new_pos = 0;
   int cfault = 0;
+  int feat_ok = 0;                  // the committed successor's features are in cfeat[A]
   int wl = 0;                       // column (lane) holding the committed successor
   const bool multi = n_legal > U;
   for (int base = 0; base < n_legal; base += U) {
@@ -467,6 +479,7 @@ __device__ void decide_game(const DevBuffers& b, const int g, const int lane, in
     int a = NONE_A;
     uint32_t my_pos = 0;
     int my_fault = 0;
+    int my_feat = 0;
     int f = 0;
     bool raises = false;
     // copy.deepcopy (stream window included) for the whole pass, by all 64 lanes: granule idx of the interleaved
@@ -495,6 +508,9 @@ __device__ void decide_game(const DevBuffers& b, const int g, const int lane, in
           fbv[i] = wf[10 + i];
         }
         s = CandEngine::action_score(wv, fbv, fa);
+        double* slot = b.cfeat + ((size_t)g * MONSOON_NUM_ACTIONS + a) * 10;
+        for (int i = 0; i < 10; i++) slot[i] = fa[i];
+        my_feat = 1;
       }
       if (write_scores) b.scores[(size_t)g * MONSOON_NUM_ACTIONS + a] = s;
       my_pos = ce.rng_pos();
@@ -520,6 +536,7 @@ __device__ void decide_game(const DevBuffers& b, const int g, const int lane, in
       wl = __ffsll((long long)bal) - 1;
       new_pos = __shfl(my_pos, wl);
       cfault = __shfl(my_fault, wl);
+      feat_ok = __shfl(my_feat, wl);
       if (multi) {
         __syncthreads();
         for (int c = lane; c < SG; c += 64) bestcol[c] = priv[c * U + wl];
@@ -550,6 +567,7 @@ __device__ void decide_game(const DevBuffers& b, const int g, const int lane, in
     meta.last_action = (uint8_t)A;
     int executed = n_legal;   // every legal action is stepped exactly once; the commit re-executes nothing
     meta.lookahead += (uint32_t)executed;
+    meta.flags = (uint8_t)((meta.flags & ~2) | (feat_ok ? 2 : 0));
     meta.decided++;   // statistics are per-game fields reduced on demand (k_stats): no same-address atomics here
     if (cfault) {
       // evo/fitness.py:208-210: an exception while applying the action ends the game as a draw
@@ -743,7 +761,7 @@ const char* monsoon_last_error(monsoon_t* h) { return h ? h->err.c_str() : g_cre
 void monsoon_destroy(monsoon_t* h) {
   if (!h) return;
   hipSetDevice(h->device);
-  void* ptrs[] = {h->b.state, h->b.rng_out, h->b.rng_mt, h->b.meta, h->b.weights, h->b.stats, h->b.scores, h->b.best, h->b.prof, h->b.pop,
+  void* ptrs[] = {h->b.state, h->b.rng_out, h->b.rng_mt, h->b.meta, h->b.weights, h->b.stats, h->b.scores, h->b.best, h->b.prof, h->b.pop, h->b.cfeat,
                   h->d_bytes, h->d_decks, h->d_factions, h->d_seeds, h->d_masks, h->d_i32, h->d_f64, h->d_p1, h->d_p2, h->d_int};
   for (void* p : ptrs)
     if (p) hipFree(p);
@@ -808,6 +826,7 @@ int monsoon_create(const monsoon_config* cfg, monsoon_t** out) {
   HIP_TRY(h, hipMalloc(&h->b.stats, ST_WORDS * sizeof(unsigned long long)));
   HIP_TRY(h, hipMemset(h->b.stats, 0, ST_WORDS * sizeof(unsigned long long)));
   HIP_TRY(h, hipMalloc(&h->b.best, cap * sizeof(double)));
+  HIP_TRY(h, hipMalloc(&h->b.cfeat, cap * MONSOON_NUM_ACTIONS * 10 * sizeof(double)));
   HIP_TRY(h, hipMalloc(&h->b.pop, 2 * 8 * 32 * sizeof(int)));
   HIP_TRY(h, hipMemset(h->b.pop, 0, 2 * 8 * 32 * sizeof(int)));
 #if defined(MSB_PROF) && MSB_PROF
