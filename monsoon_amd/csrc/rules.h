@@ -201,15 +201,15 @@ struct Engine {
   MSB_HD MSB_INL int phase() const { return m.ld8(H_PHASE); }
 
   MSB_HD MSB_INL int pl(int order, int f) const { return OFF_PL + order * PL_SIZE + f; }
-  MSB_HD MSB_INL int pl_base(int o) const { return m.ld16(pl(o, P_BASE)); }
-  MSB_HD MSB_INL void set_pl_base(int o, int v) { m.st16(pl(o, P_BASE), v); }
-  MSB_HD MSB_INL int pl_mana(int o) const { return m.ld16(pl(o, P_MANA)); }
-  MSB_HD MSB_INL void set_pl_mana(int o, int v) { m.st16(pl(o, P_MANA), v); }
-  MSB_HD MSB_INL int pl_maxmana(int o) const { return m.ld16(pl(o, P_MAXMANA)); }
-  MSB_HD MSB_INL int pl_front(int o) const { return m.ld8(pl(o, P_FRONT)); }
-  MSB_HD MSB_INL void set_pl_front(int o, int v) { m.st8(pl(o, P_FRONT), v); }
-  MSB_HD MSB_INL int pl_hand_n(int o) const { return m.ld8(pl(o, P_HAND_N)); }
-  MSB_HD MSB_INL int pl_deck_n(int o) const { return m.ld8(pl(o, P_DECK_N)); }
+  MSB_HD MSB_INL int pl_base(int o) const { return m.ld16g(pg(o) + (P_BASE >> 4), P_BASE & 15); }
+  MSB_HD MSB_INL void set_pl_base(int o, int v) { m.st16g(pg(o) + (P_BASE >> 4), P_BASE & 15, v); }
+  MSB_HD MSB_INL int pl_mana(int o) const { return m.ld16g(pg(o) + (P_MANA >> 4), P_MANA & 15); }
+  MSB_HD MSB_INL void set_pl_mana(int o, int v) { m.st16g(pg(o) + (P_MANA >> 4), P_MANA & 15, v); }
+  MSB_HD MSB_INL int pl_maxmana(int o) const { return m.ld16g(pg(o) + (P_MAXMANA >> 4), P_MAXMANA & 15); }
+  MSB_HD MSB_INL int pl_front(int o) const { return m.ld8g(pg(o) + (P_FRONT >> 4), P_FRONT & 15); }
+  MSB_HD MSB_INL void set_pl_front(int o, int v) { m.st8g(pg(o) + (P_FRONT >> 4), P_FRONT & 15, v); }
+  MSB_HD MSB_INL int pl_hand_n(int o) const { return m.ld8g(pg(o) + (P_HAND_N >> 4), P_HAND_N & 15); }
+  MSB_HD MSB_INL int pl_deck_n(int o) const { return m.ld8g(pg(o) + (P_DECK_N >> 4), P_DECK_N & 15); }
   // ---- hand / deck lists ---------------------------------------------------------------------
   // hand_ref/deck_ref: byte offset of the card-instance record {card, cost, flags, x} at a list position;
   // deck_wref: offset of that card's weight.  Standard record: values stored in place.  Extended record:
@@ -243,11 +243,27 @@ struct Engine {
   MSB_HD MSB_INL int deck_cost(int o, int i) const { return m.ld8(deck_ref(o, i) + 1); }
   MSB_HD MSB_INL int deck_flags(int o, int i) const { return m.ld8(deck_ref(o, i) + 2); }
   MSB_HD MSB_INL int deck_x(int o, int i) const { return m.ld8(deck_ref(o, i) + 3); }
-  MSB_HD MSB_INL double deck_w(int o, int i) const { return m.ldf(deck_wref(o, i)); }
-  MSB_HD MSB_INL void set_deck_w(int o, int i, double w) { m.stf(deck_wref(o, i), w); }
+  // weight slot of deck position i (standard) / of the object listed there (extended), in (granule, offset) form
+#if defined(MSB_EXT) && MSB_EXT
+  MSB_HD MSB_INL int deck_wslot(int o, int i) const { return deck_id(o, i); }
+#else
+  MSB_HD MSB_INL int deck_wslot(int o, int i) const { return i; }
+#endif
+  static_assert(P_WEIGHT % 16 == 0 && E_PATH % 16 == 0, "granule-aligned arrays");
+  MSB_HD MSB_INL double deck_w(int o, int i) const {
+    int k = deck_wslot(o, i);
+    return m.ldfg(pg(o) + P_WEIGHT / 16 + (k >> 1), 8 * (k & 1));
+  }
+  MSB_HD MSB_INL void set_deck_w(int o, int i, double w) {
+    int k = deck_wslot(o, i);
+    m.stfg(pg(o) + P_WEIGHT / 16 + (k >> 1), 8 * (k & 1), w);
+  }
+  // packed path of entity e (u32[NUM_ENT] after the entity granules)
+  MSB_HD MSB_INL uint32_t e_path(int e) const { return m.ld32g(E_PATH / 16 + (e >> 2), 4 * (e & 3)); }
+  MSB_HD MSB_INL void e_set_path(int e, uint32_t v) { m.st32g(E_PATH / 16 + (e >> 2), 4 * (e & 3), v); }
   // strength attribute of a card instance in hand/deck (see CF_ALIAS / CF_STR in state.h)
   MSB_HD MSB_INL int inst_strength(int card, int fl, int x) const {
-    if (fl & CF_ALIAS) return m.ld16(ent(x) + EO_STR);
+    if (fl & CF_ALIAS) return m.ld16g(eg(x), EO_STR);
     if (fl & (CF_STR | CF_XBASE)) return x;
     return card < NUM_CARDS ? g_cards[card].strength : 0;
   }
@@ -341,38 +357,43 @@ struct Engine {
   MSB_HD MSB_INL void board_put(int tile, int slot) { m.st8(OFF_BOARD + tile, slot); }
 
   MSB_HD MSB_INL static int ent(int e) { return OFF_ENT + ENT_SIZE * e; }
-  MSB_HD MSB_INL int e_card(int e) const { return m.ld8(ent(e) + EO_CARD); }
-  MSB_HD MSB_INL int e_flags(int e) const { return m.ld8(ent(e) + EO_FLAGS); }
-  MSB_HD MSB_INL int e_owner(int e) const { return m.ld8(ent(e) + EO_FLAGS) & EF_OWNER; }
-  MSB_HD MSB_INL bool e_ff(int e) const { return (m.ld8(ent(e) + EO_FLAGS) & EF_FF) != 0; }
+  // granule index of entity e / of player o's block: field accesses go through (granule, offset-in-granule), which
+  // costs one address instruction on the lane-interleaved LDS image instead of four for a byte offset
+  static_assert(OFF_ENT % 16 == 0 && ENT_SIZE == 16 && OFF_PL % 16 == 0 && PL_SIZE % 16 == 0, "granule-aligned blocks");
+  MSB_HD MSB_INL static int eg(int e) { return OFF_ENT / 16 + e; }
+  MSB_HD MSB_INL static int pg(int order) { return OFF_PL / 16 + order * (PL_SIZE / 16); }
+  MSB_HD MSB_INL int e_card(int e) const { return m.ld8g(eg(e), EO_CARD); }
+  MSB_HD MSB_INL int e_flags(int e) const { return m.ld8g(eg(e), EO_FLAGS); }
+  MSB_HD MSB_INL int e_owner(int e) const { return m.ld8g(eg(e), EO_FLAGS) & EF_OWNER; }
+  MSB_HD MSB_INL bool e_ff(int e) const { return (m.ld8g(eg(e), EO_FLAGS) & EF_FF) != 0; }
   MSB_HD MSB_INL void e_set_flag(int e, int bit, bool on) {
-    int f = m.ld8(ent(e) + EO_FLAGS);
-    m.st8(ent(e) + EO_FLAGS, on ? (f | bit) : (f & ~bit));
+    int f = m.ld8g(eg(e), EO_FLAGS);
+    m.st8g(eg(e), EO_FLAGS, on ? (f | bit) : (f & ~bit));
   }
-  MSB_HD MSB_INL P e_pos(int e) const { return tile_p(m.ld8(ent(e) + EO_POS)); }
-  MSB_HD MSB_INL void e_set_pos(int e, P p) { m.st8(ent(e) + EO_POS, p_tile(p)); }
-  MSB_HD MSB_INL int e_mov(int e) const { return m.ld8(ent(e) + EO_MOV); }
-  MSB_HD MSB_INL int e_str(int e) const { return m.ld16(ent(e) + EO_STR); }
-  MSB_HD MSB_INL void e_set_str(int e, int v) { m.st16(ent(e) + EO_STR, v); }
-  MSB_HD MSB_INL int e_dmg(int e) const { return m.ld16(ent(e) + EO_DMG); }
-  MSB_HD MSB_INL void e_set_dmg(int e, int v) { m.st16(ent(e) + EO_DMG, v); }
-  MSB_HD MSB_INL int e_st(int e, int s) const { return m.ld8(ent(e) + EO_ST + s); }
+  MSB_HD MSB_INL P e_pos(int e) const { return tile_p(m.ld8g(eg(e), EO_POS)); }
+  MSB_HD MSB_INL void e_set_pos(int e, P p) { m.st8g(eg(e), EO_POS, p_tile(p)); }
+  MSB_HD MSB_INL int e_mov(int e) const { return m.ld8g(eg(e), EO_MOV); }
+  MSB_HD MSB_INL int e_str(int e) const { return m.ld16g(eg(e), EO_STR); }
+  MSB_HD MSB_INL void e_set_str(int e, int v) { m.st16g(eg(e), EO_STR, v); }
+  MSB_HD MSB_INL int e_dmg(int e) const { return m.ld16g(eg(e), EO_DMG); }
+  MSB_HD MSB_INL void e_set_dmg(int e, int v) { m.st16g(eg(e), EO_DMG, v); }
+  MSB_HD MSB_INL int e_st(int e, int s) const { return m.ld8g(eg(e), EO_ST + s); }
   MSB_HD MSB_INL void e_st_add(int e, int s) {
-    int c = m.ld8(ent(e) + EO_ST + s);
+    int c = m.ld8g(eg(e), EO_ST + s);
     if (c >= 255) {
       set_fault(FAULT_STATUS_SAT);
       return;
     }
-    m.st8(ent(e) + EO_ST + s, c + 1);
+    m.st8g(eg(e), EO_ST + s, c + 1);
   }
   // list.remove(x) raises ValueError when x is absent
   MSB_HD MSB_INL void e_st_remove(int e, int s) {
-    int c = m.ld8(ent(e) + EO_ST + s);
+    int c = m.ld8g(eg(e), EO_ST + s);
     if (c == 0) {
       set_fault(FAULT_PY_EXCEPTION);
       return;
     }
-    m.st8(ent(e) + EO_ST + s, c - 1);
+    m.st8g(eg(e), EO_ST + s, c - 1);
   }
 
   // ---- card statics (tokens: board.py:298-322) -------------------------------------------------
@@ -393,7 +414,7 @@ struct Engine {
   }
   // static facts of the entity's card, cached in the entity record when it is created (no card-table
   // load -- a global-memory round trip -- inside the selectors and the movement loop)
-  MSB_HD MSB_INL int e_kind(int e) const { return m.ld8(ent(e) + EO_KIND); }
+  MSB_HD MSB_INL int e_kind(int e) const { return m.ld8g(eg(e), EO_KIND); }
   MSB_HD MSB_INL bool e_is_unit(int e) const { return (e_kind(e) & EK_UNIT) != 0; }
   MSB_HD MSB_INL bool e_has_ability(int e) const { return (e_kind(e) & EK_ABILITY) != 0; }
   MSB_HD MSB_INL int e_card_trigger(int e) const { return ((e_kind(e) >> 2) & 15) - 1; }   // card_trigger(e_card(e))
@@ -455,14 +476,14 @@ struct Engine {
   MSB_HD MSB_INL uint32_t empty_mask() const { return ~occ_mask() & 0xFFFFFu; }
   MSB_HD MSB_INL void begin_step() {
     MSB_SCOPE(PS_BEGIN_STEP);
+    // one shift per tile, no compare: an empty tile (0xFF) sets bit 31, which is not an entity slot
+    static_assert((SLOT_NONE & 31) >= NUM_ENT, "the empty marker must map outside the slot bits");
     uint32_t used = 0;
     for (int y = 0; y < 5; y++) {
       uint32_t row = board_row(y);
-      for (int x = 0; x < 4; x++) {
-        uint32_t s = (row >> (8 * x)) & 0xff;
-        if (s != (uint32_t)SLOT_NONE) used |= 1u << s;
-      }
+      for (int x = 0; x < 4; x++) used |= 1u << ((row >> (8 * x)) & 31u);
     }
+    used &= (1u << NUM_ENT) - 1u;
     m.st32(H_USED, used);
     // a hand/deck entry aliasing an entity that has left the board keeps that object's last strength
     if (m.ld8(H_OBSFAULT) & GF_ALIAS) {
@@ -500,8 +521,8 @@ struct Engine {
     // card | flags<<8 | pos<<16 | mov<<24 ; st0..st3 = 0 ; st4 = 0, move_id = 0, strength<<16 ; dmg = 0, path_n = 0
     msb_u32x4 g = {(uint32_t)card | ((uint32_t)((owner ? EF_OWNER : 0) | (ff ? EF_FF : 0)) << 8) | ((uint32_t)(movement & 0xff) << 24),
                    0u, (uint32_t)(strength & 0xffff) << 16, (uint32_t)kind_byte(card) << 24};
-    m.st128(ent(e), g);
-    m.st32(E_PATH + 4 * e, 0);
+    m.st128g(eg(e), g);
+    e_set_path(e, 0);
     if (REM_LISTS) m.st8(E_REM + e, REM_NONE);
     return e;
   }
@@ -561,7 +582,7 @@ struct Engine {
     int r = rem_rec(list, i);
     m.st8(r + 0, e_card(e));
     m.st8(r + 1, e_flags(e));
-    m.st8(r + 2, m.ld8(ent(e) + EO_POS));
+    m.st8(r + 2, m.ld8g(eg(e), EO_POS));
     m.st8(r + 3, e_mov(e));
     for (int s = 0; s < 5; s++) m.st8(r + 4 + s, e_st(e, s));
     int str = e_str(e);
@@ -583,8 +604,8 @@ struct Engine {
     int str = (int16_t)(m.ld8(r + 9) | (m.ld8(r + 10) << 8));
     int e = new_entity(card, fl & EF_OWNER, str, m.ld8(r + 3), (fl & EF_FF) != 0);
     if (fault()) return e;
-    m.st8(ent(e) + EO_FLAGS, fl);
-    for (int s = 0; s < 5; s++) m.st8(ent(e) + EO_ST + s, m.ld8(r + 4 + s));
+    m.st8g(eg(e), EO_FLAGS, fl);
+    for (int s = 0; s < 5; s++) m.st8g(eg(e), EO_ST + s, m.ld8(r + 4 + s));
     m.st8(E_REM + e, m.ld8(r + 11));   // the nested memory now belongs to the restored object
     board_set(tile_p(m.ld8(r + 2)), e);
     return e;
@@ -650,7 +671,7 @@ struct Engine {
       occ &= occ - 1;
       const unsigned long long bw = tile < 8 ? b01 : (tile < 16 ? b23 : (unsigned long long)r4);
       const int e = (int)((bw >> (8 * (tile & 7))) & 0xff);
-      const msb_u32x4 g = m.ld128(ent(e));   // the whole entity in one LDS read
+      const msb_u32x4 g = m.ld128g(eg(e));   // the whole entity in one LDS read
       int str = (int)(int16_t)(g[2] >> 16);
       if (str <= 0) continue;
       int c = (int)(g[0] & 0xff);
@@ -974,7 +995,7 @@ struct Engine {
     MSB_SCOPE(PS_DESTROY);
     if (e_is_unit(e)) {
       board_set(e_pos(e), -1);
-      m.st8(ent(e) + EO_PATHN, 0);
+      m.st8g(eg(e), EO_PATHN, 0);
       e_set_dmg(e, e_str(e));
       if (e_card_trigger(e) == TR_ON_DEATH) {
         push_trigger(e, src);
@@ -1093,8 +1114,8 @@ struct Engine {
       }
       position = dest;
     }
-    m.st32(E_PATH + 4 * e, packed);
-    m.st8(ent(e) + EO_PATHN, n);
+    e_set_path(e, packed);
+    m.st8g(eg(e), EO_PATHN, n);
   }
 
   // Unit.move, unit.py:124-203
@@ -1116,8 +1137,8 @@ struct Engine {
     m.st8(H_DEPTH, d);
   }
   MSB_HD MSB_INL void move_body(int e) {
-    int current_id = (m.ld8(ent(e) + EO_MOVEID) + 1) & 0xff;
-    m.st8(ent(e) + EO_MOVEID, current_id);
+    int current_id = (m.ld8g(eg(e), EO_MOVEID) + 1) & 0xff;
+    m.st8g(eg(e), EO_MOVEID, current_id);
     if (phase() == PH_TURN_START) {
       if (e_st(e, ST_POISONED) > 0)
         entity_deal_damage(e, 1, false, false);
@@ -1129,14 +1150,14 @@ struct Engine {
         return;
       }
     }
-    if (m.ld8(ent(e) + EO_PATHN) == 0) return;
+    if (m.ld8g(eg(e), EO_PATHN) == 0) return;
     int trig = e_trigger(e);
     if (trig == TR_BEFORE_MOVING && !e_disabled(e)) run_ability(e, -1, PK_NONE, true);
     if (fault()) return;
     if (e_frozen(e)) return;
     // `for destination in self.path` iterates the list object bound now (fact #5)
-    int n = m.ld8(ent(e) + EO_PATHN);
-    uint32_t path = m.ld32(E_PATH + 4 * e);
+    int n = m.ld8g(eg(e), EO_PATHN);
+    uint32_t path = e_path(e);
     int owner = e_owner(e);  // self.player is re-read by the reference; convert() may change it
     for (int i = 0; i < n; i++) {
       P dest = p_unpack((path >> (8 * i)) & 0xff);
@@ -1171,7 +1192,7 @@ struct Engine {
           is_attacked = true;
         }
       }
-      if (current_id != m.ld8(ent(e) + EO_MOVEID)) return;
+      if (current_id != m.ld8g(eg(e), EO_MOVEID)) return;
       if (at(dest) == AT_NONE && e_str(e) > 0) {
         board_set(e_pos(e), -1);
         board_set(dest, e);
@@ -1203,9 +1224,9 @@ struct Engine {
   // Unit.gain_speed, unit.py:277-280
   MSB_HD MSB_INL void gain_speed(int e, int amount) {
     int mv = e_mov(e);
-    m.st8(ent(e) + EO_MOV, mv + amount);
+    m.st8g(eg(e), EO_MOV, mv + amount);
     set_path(e, e_resolving_play(e));
-    m.st8(ent(e) + EO_MOV, mv);
+    m.st8g(eg(e), EO_MOV, mv);
   }
   // Unit.command, unit.py:282-289
   MSB_HD MSB_A_MISC void command(int e) {
@@ -1285,8 +1306,8 @@ struct Engine {
       return;
     }
     if (n > 0) {
-      m.st32(E_PATH + 4 * e, packed);
-      m.st8(ent(e) + EO_PATHN, n);
+      e_set_path(e, packed);
+      m.st8g(eg(e), EO_PATHN, n);
       move(e);
     }
   }
@@ -1395,19 +1416,17 @@ struct Engine {
   }
   // Board.add_to_history, board.py:324-325 (only the last four are observable)
   MSB_HD MSB_INL void add_history(int owner, int card) {
+    // four {owner, card} byte pairs, oldest first, as one 64-bit word: append, or drop the oldest and append
     int n = m.ld8(H_HIST_N);
+    uint64_t h = m.ld64(H_HIST);
+    const uint64_t entry = (uint64_t)(owner & 0xff) | ((uint64_t)(card & 0xff) << 8);
     if (n < 4) {
-      m.st8(H_HIST + 2 * n, owner);
-      m.st8(H_HIST + 2 * n + 1, card);
+      h = (h & ~(0xffffull << (16 * n))) | (entry << (16 * n));
       m.st8(H_HIST_N, n + 1);
     } else {
-      for (int i = 0; i < 3; i++) {
-        m.st8(H_HIST + 2 * i, m.ld8(H_HIST + 2 * (i + 1)));
-        m.st8(H_HIST + 2 * i + 1, m.ld8(H_HIST + 2 * (i + 1) + 1));
-      }
-      m.st8(H_HIST + 6, owner);
-      m.st8(H_HIST + 7, card);
+      h = (h >> 16) | (entry << 48);
     }
+    m.st64(H_HIST, h);
   }
   // Player.play, player.py:68-77.  has_pos=false <=> position None
   MSB_HD MSB_INL void player_play(int o, int index, P position, bool has_pos) {
@@ -1481,7 +1500,7 @@ struct Engine {
       m.st32(OFF_BOARD + 4 * y, v);
       for (int x = 0; x < 4; x++) {
         uint32_t s = (v >> (8 * x)) & 0xff;
-        if (s != (uint32_t)SLOT_NONE) m.st8(ent((int)s) + EO_POS, y * 4 + x);
+        if (s != (uint32_t)SLOT_NONE) m.st8g(eg((int)s), EO_POS, y * 4 + x);
       }
     }
   }
@@ -1510,7 +1529,7 @@ struct Engine {
     for (int i = 0; i < ns; i++) {
       int s = snap.get(i);
       // structure.is_at_turn_start: token structures and b001 run the empty base ability
-      if (e_card_trigger(s) == TR_TURN_START) run_ability(s, -1, m.ld8(ent(s) + EO_POS) /*unused*/, true);
+      if (e_card_trigger(s) == TR_TURN_START) run_ability(s, -1, m.ld8g(eg(s), EO_POS) /*unused*/, true);
       if (fault()) return;
     }
     snap = get_targets(ncp, mk_tgt(TK_UNIT, TS_FRIENDLY), PK_NONE);
@@ -1752,7 +1771,7 @@ struct Engine {
     m.st64(H_RNGNXT, rn);
     m.st16(H_RNGPOS, (int)rp);
     for (int t = 0; t < 20; t++) board_put(t, SLOT_NONE);
-    for (int e = 0; e < NUM_ENT; e++) m.st8(ent(e) + EO_CARD, CARD_NONE);
+    for (int e = 0; e < NUM_ENT; e++) m.st8g(eg(e), EO_CARD, CARD_NONE);
     if (REM_LISTS)
       for (int e = 0; e < NUM_ENT; e++) m.st8(E_REM + e, REM_NONE);
     for (int i = 0; i < 4; i++) {

@@ -144,6 +144,17 @@ struct FlatMem {
     return v;
   }
   MSB_HD MSB_INL void st128(int o, msb_u32x4 v) { __builtin_memcpy(p + o, &v, 16); }
+  // (granule, byte within the granule) forms
+  MSB_HD MSB_INL int ld8g(int g, int k) const { return ld8(g * 16 + k); }
+  MSB_HD MSB_INL void st8g(int g, int k, int v) { st8(g * 16 + k, v); }
+  MSB_HD MSB_INL int ld16g(int g, int k) const { return ld16(g * 16 + k); }
+  MSB_HD MSB_INL void st16g(int g, int k, int v) { st16(g * 16 + k, v); }
+  MSB_HD MSB_INL msb_u32x4 ld128g(int g) const { return ld128(g * 16); }
+  MSB_HD MSB_INL void st128g(int g, msb_u32x4 v) { st128(g * 16, v); }
+  MSB_HD MSB_INL uint32_t ld32g(int g, int k) const { return ld32(g * 16 + k); }
+  MSB_HD MSB_INL void st32g(int g, int k, uint32_t v) { st32(g * 16 + k, v); }
+  MSB_HD MSB_INL double ldfg(int g, int k) const { return ldf(g * 16 + k); }
+  MSB_HD MSB_INL void stfg(int g, int k, double v) { stf(g * 16 + k, v); }
 };
 
 #if defined(__HIPCC__)
@@ -177,6 +188,21 @@ struct LaneMem {   // this lane's private record among LANES interleaved ones
   MSB_HD MSB_INL static void st64(int o, uint64_t v) { *(MSB_AS_LDS uint64_t*)b(o) = v; }
   MSB_HD MSB_INL static msb_u32x4 ld128(int o) { return *(MSB_AS_LDS const msb_u32x4*)b(o); }
   MSB_HD MSB_INL static void st128(int o, msb_u32x4 v) { *(MSB_AS_LDS msb_u32x4*)b(o) = v; }
+  // (granule, byte within the granule): granule * (LANES*16) + lane*16 + BASE + k -- one shift-add for a dynamic
+  // granule, the rest folds into the instruction's immediate offset
+  MSB_HD MSB_INL static MSB_AS_LDS uint8_t* gb(int g, int k) {
+    return (MSB_AS_LDS uint8_t*)(uintptr_t)(BASE + g * (LANES * 16) + k + (int)__builtin_amdgcn_workitem_id_x() * 16);
+  }
+  MSB_HD MSB_INL static int ld8g(int g, int k) { return *gb(g, k); }
+  MSB_HD MSB_INL static void st8g(int g, int k, int v) { *gb(g, k) = (uint8_t)v; }
+  MSB_HD MSB_INL static int ld16g(int g, int k) { return *(MSB_AS_LDS const int16_t*)gb(g, k); }
+  MSB_HD MSB_INL static void st16g(int g, int k, int v) { *(MSB_AS_LDS int16_t*)gb(g, k) = (int16_t)v; }
+  MSB_HD MSB_INL static msb_u32x4 ld128g(int g) { return *(MSB_AS_LDS const msb_u32x4*)gb(g, 0); }
+  MSB_HD MSB_INL static void st128g(int g, msb_u32x4 v) { *(MSB_AS_LDS msb_u32x4*)gb(g, 0) = v; }
+  MSB_HD MSB_INL static uint32_t ld32g(int g, int k) { return *(MSB_AS_LDS const uint32_t*)gb(g, k); }
+  MSB_HD MSB_INL static void st32g(int g, int k, uint32_t v) { *(MSB_AS_LDS uint32_t*)gb(g, k) = v; }
+  MSB_HD MSB_INL static double ldfg(int g, int k) { return *(MSB_AS_LDS const double*)gb(g, k); }
+  MSB_HD MSB_INL static void stfg(int g, int k, double v) { *(MSB_AS_LDS double*)gb(g, k) = v; }
 };
 template <int BASE>
 struct SharedMem {   // one contiguous record read by every lane of the wave (LDS broadcast)
@@ -193,6 +219,16 @@ struct SharedMem {   // one contiguous record read by every lane of the wave (LD
   MSB_HD MSB_INL static void st64(int o, uint64_t v) { *(MSB_AS_LDS uint64_t*)b(o) = v; }
   MSB_HD MSB_INL static msb_u32x4 ld128(int o) { return *(MSB_AS_LDS const msb_u32x4*)b(o); }
   MSB_HD MSB_INL static void st128(int o, msb_u32x4 v) { *(MSB_AS_LDS msb_u32x4*)b(o) = v; }
+  MSB_HD MSB_INL static int ld8g(int g, int k) { return ld8(g * 16 + k); }
+  MSB_HD MSB_INL static void st8g(int g, int k, int v) { st8(g * 16 + k, v); }
+  MSB_HD MSB_INL static int ld16g(int g, int k) { return ld16(g * 16 + k); }
+  MSB_HD MSB_INL static void st16g(int g, int k, int v) { st16(g * 16 + k, v); }
+  MSB_HD MSB_INL static msb_u32x4 ld128g(int g) { return ld128(g * 16); }
+  MSB_HD MSB_INL static void st128g(int g, msb_u32x4 v) { st128(g * 16, v); }
+  MSB_HD MSB_INL static uint32_t ld32g(int g, int k) { return ld32(g * 16 + k); }
+  MSB_HD MSB_INL static void st32g(int g, int k, uint32_t v) { st32(g * 16 + k, v); }
+  MSB_HD MSB_INL static double ldfg(int g, int k) { return ldf(g * 16 + k); }
+  MSB_HD MSB_INL static void stfg(int g, int k, double v) { stf(g * 16 + k, v); }
 };
 #endif
 
