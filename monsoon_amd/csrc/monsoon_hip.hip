@@ -437,7 +437,15 @@ __device__ void decide_game(const DevBuffers& b, const int g, const int lane, in
 
   PROF_MARK(0);   // stage
   const msb_u64x4 lm = pe.legal_mask_v();
-  const uint64_t mask[3] = {lm[0], lm[1], lm[2]};
+  // the legal set as wave-uniform scalars; `rem` loses the U lowest actions after every pass, so a lane finds its
+  // action among the first U set bits (at most U - 1 steps, on the scalar unit for the common part)
+  auto uni64 = [](unsigned long long v) {
+    unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v);
+    unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v >> 32));
+    return ((unsigned long long)hi << 32) | lo;
+  };
+  const uint64_t mask[3] = {uni64(lm[0]), uni64(lm[1]), uni64(lm[2])};
+  uint64_t rem[3] = {mask[0], mask[1], mask[2]};
   const int n_legal = __popcll(mask[0]) + __popcll(mask[1]) + __popcll(mask[2]);
   PROF_MARK(1);   // legal mask
   const bool before_raises = pe.observation_raises();
@@ -491,7 +499,12 @@ __device__ void decide_game(const DevBuffers& b, const int g, const int lane, in
         if ((idx & (U - 1)) < n_act) priv[idx] = par[idx / U];
       __syncthreads();
     }
-    if (lane < U && k < n_legal) a = nth_set_bit(mask, k);
+    if (lane < U && k < n_legal) a = nth_set_bit(rem, lane);
+    for (int i = 0; i < U; i++) {   // uniform: drop this pass's actions
+      if (rem[0]) rem[0] &= rem[0] - 1;
+      else if (rem[1]) rem[1] &= rem[1] - 1;
+      else rem[2] &= rem[2] - 1;
+    }
     PROF_MARK(3);   // clone
     if (lane < U && k < n_legal) {
       ce.step(a);
@@ -518,9 +531,10 @@ __device__ void decide_game(const DevBuffers& b, const int g, const int lane, in
     }
     PROF_MARK(5);   // after-features + score
     // first maximum over the ascending legal list == (max score, then min action id)
+    // only lanes 0..U-1 hold candidates: butterfly over those, then broadcast lane 0's result to the wave
     double cs = s;
     int ca = a;
-    for (int off = 32; off >= 1; off >>= 1) {
+    for (int off = U / 2; off >= 1; off >>= 1) {
       double os = __shfl_xor(cs, off);
       int oa = __shfl_xor(ca, off);
       bool take = (oa != NONE_A) && (ca == NONE_A || os > cs || (os == cs && oa < ca));
@@ -529,14 +543,21 @@ __device__ void decide_game(const DevBuffers& b, const int g, const int lane, in
         ca = oa;
       }
     }
+    {
+      const unsigned long long bits = (unsigned long long)__double_as_longlong(cs);
+      const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)bits);
+      const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(bits >> 32));
+      cs = __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+      ca = __builtin_amdgcn_readfirstlane(ca);
+    }
     if (ca != NONE_A && (run_a == NONE_A || cs > run_s)) {   // later passes hold larger action ids: strict >
       run_s = cs;
       run_a = ca;
       unsigned long long bal = __ballot(a == ca);
       wl = __ffsll((long long)bal) - 1;
-      new_pos = __shfl(my_pos, wl);
-      cfault = __shfl(my_fault, wl);
-      feat_ok = __shfl(my_feat, wl);
+      new_pos = (uint32_t)__builtin_amdgcn_readlane((int)my_pos, wl);
+      cfault = __builtin_amdgcn_readlane(my_fault, wl);
+      feat_ok = __builtin_amdgcn_readlane(my_feat, wl);
       if (multi) {
         __syncthreads();
         for (int c = lane; c < SG; c += 64) bestcol[c] = priv[c * U + wl];
