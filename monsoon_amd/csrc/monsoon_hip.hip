@@ -1,7 +1,7 @@
 // libmonsoon_hip.so -- MI355X (gfx950) batched Stormbound engine: kernels + C ABI (include/monsoon.h).
 //
 // Execution model
-//   * Hot kernel k_decide<U>: ONE WAVEFRONT PER GAME.  The game's record (960 B) is staged from
+//   * Hot kernel k_decide<U>: ONE WAVEFRONT PER GAME.  The game's record (992 B) is staged from
 //     HBM into LDS with one coalesced pass; the legal-action mask and the "before" features are
 //     evaluated on that shared copy (LDS broadcast reads); then up to U candidate actions are
 //     advanced at once, lane l stepping its own private copy of the state.  The private copies are

@@ -179,6 +179,33 @@ def test_rollout_schedule_two_weight_vectors(engines):
     assert np.array_equal(counts, ocounts)
 
 
+def test_per_game_fault_codes_equal_cpu_replay(engines):
+    """monsoon_game_faults: the code that stopped each game (reference-level exceptions included) equals the CPU
+    replay's, on random 12-card decks where such stops are common."""
+    from monsoon_amd.cards import CARD_INDEX, supported_pool
+    pool = np.array([CARD_INDEX[c] for c in supported_pool()], dtype=np.uint8)
+    n = 192
+    pairs = np.zeros((n, 2, 12), dtype=np.uint8)
+    for g in range(n):
+        rs = np.random.RandomState(g ^ 0x9E3779B9)
+        pairs[g, 0], pairs[g, 1] = rs.choice(pool, 12, replace=False), rs.choice(pool, 12, replace=False)
+    m = np.zeros(n, dtype=[("p1", "<i4"), ("p2", "<i4"), ("seed", "<u4"), ("deck", "<u4")])
+    m["seed"] = 7000 + np.arange(n)
+    m["deck"] = np.arange(n)
+    eng = engines(256)
+    counts, results, steps = eng.rollout(W0.reshape(1, 10), m, pairs, 150, want_results=True)
+    faults = eng.game_faults()
+    orc = oracle_lib.Oracle(1)
+    ofaults = np.zeros(n, dtype=np.uint8)
+    for g in range(n):
+        orc.reset(0, int(m["seed"][g]), pairs[g, 0], pairs[g, 1])
+        r = orc.rollout(0, W0, W0, 150)
+        ofaults[g] = r["fault"]
+        assert (r["result"], r["steps"]) == (results[g], steps[g]), g
+    assert np.array_equal(faults, ofaults)
+    assert (faults != 0).sum() >= 5 and (faults >= 16).sum() == 0   # exceptions do occur here; none is a build limit
+
+
 def test_fitness_with_deck_schedule_equals_cpu_replay():
     """Seam F with a DeckEvolutionConfig in its explore phase (a deck pair per game): fitness from the HIP rollout
     equals the fitness from the CPU replay of the same schedule."""
