@@ -256,6 +256,33 @@ def test_full_size_65536_games_bit_exact_and_deterministic(engines):
     assert eng.stats()["capacity_faults"] == 0
 
 
+def test_random_deck_rollouts_extended_build_bit_exact(engines):
+    """A slice of BASELINE configs[4] (C5): 2 048 games, every game its own pair of 12-card decks drawn from the 109
+    observable cards (ua20 and b005 included -> extended build), heuristic self-play to 200 decisions; results,
+    decision counts, fault codes and final canonical records equal the CPU replay."""
+    from monsoon_amd.cards import CARD_IDS
+    pool = np.array([i for i, c in enumerate(CARD_IDS) if c not in ("up01", "up02", "up03")], dtype=np.uint8)
+    n = 2048
+    pairs = np.zeros((n, 2, 12), dtype=np.uint8)
+    for g in range(n):
+        rs = np.random.RandomState(g ^ 0x9E3779B9)
+        pairs[g, 0], pairs[g, 1] = rs.choice(pool, 12, replace=False), rs.choice(pool, 12, replace=False)
+    m = np.zeros(n, dtype=[("p1", "<i4"), ("p2", "<i4"), ("seed", "<u4"), ("deck", "<u4")])
+    m["seed"] = 90000 + np.arange(n)
+    m["deck"] = np.arange(n)
+    eng = engines(n, extended=True)
+    _, results, steps = eng.rollout(W0[None], m, pairs, 200, want_results=True)
+    hashes, faults = eng.state_hash(), eng.game_faults()
+    orc = oracle_lib.Oracle(n, extended=True)
+    for g in range(n):
+        assert orc.reset(g, int(m["seed"][g]), pairs[g, 0], pairs[g, 1]) == 0
+    _, ores, osteps, ohash = orc.rollout_batch(n, W0, 200, 16)
+    assert np.array_equal(results, ores) and np.array_equal(steps, osteps)
+    assert np.array_equal(hashes, ohash)
+    # reference-level exceptions are frequent with these decks; build limits must stay rare (nested b005 memory, §2a)
+    assert (faults == 1).sum() > n // 10 and (faults >= 16).sum() < n // 10
+
+
 def test_observation_tensor_view_on_device(engines):
     """the batched observation lands in a torch-ROCm tensor without a host round trip."""
     import torch
