@@ -1,16 +1,17 @@
 // libmonsoon_hip.so -- MI355X (gfx950) batched Stormbound engine: kernels + C ABI (include/monsoon.h).
 //
 // Execution model
-//   * Hot kernel k_decide<U>: ONE WAVEFRONT PER GAME.  The game's record (992 B) is staged from
-//     HBM into LDS with one coalesced pass; the legal-action mask and the "before" features are
-//     evaluated on that shared copy (LDS broadcast reads); then up to U candidate actions are
-//     advanced at once, lane l stepping its own private copy of the state.  The private copies are
-//     word-interleaved across lanes (word w of lane l at w*U+l), so lanes touching the same field
-//     hit distinct LDS banks.  Scores are reduced with 64-lane shuffles (first maximum in
-//     ascending action order = np.argmax over the sorted legal list) and the winner's column is
-//     written back as the game's new record.  Nothing is re-executed: the committed successor IS
-//     one of the look-ahead results (when the legal set needs several passes of U lanes, the best
-//     successor so far is parked in a spare LDS column).
+//   * Hot kernel k_decide<U>: ONE WAVEFRONT PER GAME (a persistent grid of resident wavefronts, each popping game
+//     indices from its range's counter).  The game's record (992 B) is staged from HBM into LDS with one coalesced
+//     pass; the legal-action mask is evaluated on that shared copy (LDS broadcast reads), the "before" features
+//     are the ones the previous decision computed for the successor it committed; then up to U candidate actions
+//     are advanced at once, lane l stepping its own private copy of the state.  The private copies are interleaved
+//     across lanes in 16-byte granules (granule c of lane l at (c*U + l)*16), so lanes touching the same field hit
+//     distinct LDS banks and a whole entity is one ds_read_b128.  Scores are reduced with shuffles over the U
+//     candidate lanes (first maximum in ascending action order = np.argmax over the sorted legal list) and the
+//     winner's column is written back as the game's new record.  Nothing is re-executed: the committed successor
+//     IS one of the look-ahead results (when the legal set needs several passes of U lanes, the best successor so
+//     far is parked in a spare LDS column).
 //   * The game's MT19937 stream lives in HBM as two blocks of tempered outputs (current + next)
 //     plus the raw state; candidate steps read it through a private cursor, the committed
 //     cursor is stored back and the wave regenerates a block (twist in LDS) when it is used up.

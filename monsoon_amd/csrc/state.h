@@ -1,11 +1,10 @@
 // Per-game state record: byte layout + the two memory accessors the rules core runs on.
 //
-// One record = STATE_BYTES bytes, every field naturally aligned.  In HBM a batch of games is
-// stored word-interleaved (word w of game g at  w*stride + g), so that a wavefront reading the
-// same field of 64 consecutive games issues one coalesced 256-byte access.  Inside a kernel a
-// record lives in LDS, again word-interleaved across the lanes of the wave (word w of lane l at
-// w*LANES + l): all lanes touching the same field hit 64 different banks, no conflicts
-// (MI355X_MICROARCH.md, LDS: ds_read_b32 is serviced as two conflict-free 32-lane groups).
+// One record = STATE_BYTES bytes (a whole number of 16-byte granules), every field naturally aligned.  In HBM a
+// batch of games is stored record-major: the hot kernel gives a wavefront to a game, so one game's record is one
+// coalesced 16-bytes-per-lane read.  Inside a kernel a record lives in LDS; the candidate copies of a decision are
+// interleaved across the lanes of the wave in 16-byte granules (granule c of lane l at (c*LANES + l)*16): lanes
+// touching the same field hit different banks, and an entity (one granule) is a single ds_read_b128.
 //
 // What the fields restate (reference file:line):
 //   header      games/stormbound.py:304 (player), board.py:20-25 (current_player, history, triggers,
