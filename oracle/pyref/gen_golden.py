@@ -232,6 +232,7 @@ def heuristic_trace(args):
     adapter = StormboundAdapter(game)
     rec = dict(action=[], hash=[], best=[], shash=[], nlegal=[])
     steps = 0
+    fault = 0
     with contextlib.redirect_stdout(io.StringIO()):
         while not adapter.game.env.have_winner() and steps < max_turns:
             agent = agents[adapter.get_current_player()]
@@ -239,39 +240,80 @@ def heuristic_trace(args):
             scores = np.array([agent.score_action(adapter, a) for a in legal], dtype=np.float64)
             k = int(np.argmax(scores))
             a = legal[k]
-            adapter = adapter.apply_action(a)
-            steps += 1
             rec["action"].append(a)
-            rec["hash"].append(H.fnv1a64(H.canon(adapter.game.env)))
             rec["best"].append(scores[k])
             rec["shash"].append(H.fnv1a64(scores.tobytes()))
             rec["nlegal"].append(len(legal))
+            try:
+                adapter = adapter.apply_action(a)
+            except Exception:   # evo/fitness.py:208-210: the exception ends the game as a draw
+                rec["hash"].append(0)
+                fault = 1
+                steps += 1
+                break
+            steps += 1
+            rec["hash"].append(H.fnv1a64(H.canon(adapter.game.env)))
     env = adapter.game.env
     b = {int(env.board.local.order): env.board.local.strength, int(env.board.remote.order): env.board.remote.strength}
-    result = 0 if (b[1] < 0 <= b[0]) else 1 if (b[0] < 0 <= b[1]) else -1
-    return seed, rec, result
+    result = -1 if fault else (0 if (b[1] < 0 <= b[0]) else 1 if (b[0] < 0 <= b[1]) else -1)
+    return seed, rec, result, fault
 
 
-def gen_heuristic(n_games, max_turns, jobs):
-    d = H.DECKS["N12M"]
-    tasks = [(s, d, d, max_turns) for s in range(n_games)]
+def gen_heuristic(n_games, max_turns, jobs, deck0="N12M", deck1=None, seed0=0):
+    d0, d1 = H.DECKS[deck0], H.DECKS[deck1 or deck0]
+    tasks = [(seed0 + s, d0, d1, max_turns) for s in range(n_games)]
     with ProcessPoolExecutor(jobs) as ex:
         results = list(ex.map(heuristic_trace, tasks))
-    out = dict(seeds=[], offsets=[0], result=[], action=[], hash=[], best=[], shash=[], nlegal=[])
-    for seed, rec, result in results:
+    out = dict(seeds=[], offsets=[0], result=[], fault=[], action=[], hash=[], best=[], shash=[], nlegal=[])
+    for seed, rec, result, fault in results:
         out["seeds"].append(seed)
         out["result"].append(result)
+        out["fault"].append(fault)
+        for k in ("action", "hash", "best", "shash", "nlegal"):
+            out[k] += rec[k]
+        out["offsets"].append(len(out["action"]))
+    name = f"trace_heuristic_{deck0}.npz"
+    np.savez_compressed(
+        os.path.join(GOLD, name), seeds=np.array(out["seeds"], dtype=np.uint32),
+        offsets=np.array(out["offsets"], dtype=np.int64), result=np.array(out["result"], dtype=np.int8),
+        fault=np.array(out["fault"], dtype=np.uint8),
+        action=np.array(out["action"], dtype=np.uint8), hash=np.array(out["hash"], dtype=np.uint64),
+        best=np.array(out["best"], dtype=np.float64), shash=np.array(out["shash"], dtype=np.uint64),
+        nlegal=np.array(out["nlegal"], dtype=np.int16), deck=idx(d0), deck1=idx(d1), w0=W0, max_turns=np.int32(max_turns))
+    print(name, "games", n_games, "decisions", len(out["action"]), "look-ahead steps", int(np.sum(out["nlegal"])),
+          "ended by an exception", int(np.sum(out["fault"])))
+
+
+def gen_heuristic_pool(n_games, max_turns, jobs, seed0=700):
+    """Heuristic self-play on per-game random 12-card decks (standard-build pool): look-aheads and committed steps
+    that raise in the reference are common here (evo/heuristic_agent.py:48-51 -> score 0.0, evo/fitness.py:208-210)."""
+    pool = [c for c in H.CARD_IDS if c not in ("ua20", "b005", "up01", "up02", "up03")]
+    tasks, decks = [], []
+    for s in range(n_games):
+        rs = np.random.RandomState((seed0 + s) ^ 0x9E3779B9)
+        d0 = [str(c) for c in rs.choice(pool, 12, replace=False)]
+        d1 = [str(c) for c in rs.choice(pool, 12, replace=False)]
+        tasks.append((seed0 + s, d0, d1, max_turns))
+        decks.append([idx(d0), idx(d1)])
+    with ProcessPoolExecutor(jobs) as ex:
+        results = list(ex.map(heuristic_trace, tasks))
+    out = dict(seeds=[], offsets=[0], result=[], fault=[], action=[], hash=[], best=[], shash=[], nlegal=[])
+    for seed, rec, result, fault in results:
+        out["seeds"].append(seed)
+        out["result"].append(result)
+        out["fault"].append(fault)
         for k in ("action", "hash", "best", "shash", "nlegal"):
             out[k] += rec[k]
         out["offsets"].append(len(out["action"]))
     np.savez_compressed(
-        os.path.join(GOLD, "trace_heuristic_N12M.npz"), seeds=np.array(out["seeds"], dtype=np.uint32),
+        os.path.join(GOLD, "trace_heuristic_pool.npz"), seeds=np.array(out["seeds"], dtype=np.uint32),
         offsets=np.array(out["offsets"], dtype=np.int64), result=np.array(out["result"], dtype=np.int8),
+        fault=np.array(out["fault"], dtype=np.uint8),
         action=np.array(out["action"], dtype=np.uint8), hash=np.array(out["hash"], dtype=np.uint64),
         best=np.array(out["best"], dtype=np.float64), shash=np.array(out["shash"], dtype=np.uint64),
-        nlegal=np.array(out["nlegal"], dtype=np.int16), deck=idx(d), w0=W0, max_turns=np.int32(max_turns))
-    print("trace_heuristic_N12M.npz games", n_games, "decisions", len(out["action"]),
-          "look-ahead steps", int(np.sum(out["nlegal"])))
+        nlegal=np.array(out["nlegal"], dtype=np.int16), decks=np.array(decks, dtype=np.uint8), w0=W0, max_turns=np.int32(max_turns))
+    print("trace_heuristic_pool.npz games", n_games, "decisions", len(out["action"]), "look-ahead steps", int(np.sum(out["nlegal"])),
+          "ended by an exception", int(np.sum(out["fault"])))
 
 
 def gen_initial():
@@ -359,6 +401,9 @@ def main():
         "random_S12": lambda: gen_random("S12", None, 48, 300, args.jobs),
         "expert": lambda: gen_expert(48, 300, args.jobs),
         "heuristic": lambda: gen_heuristic(12, 200, args.jobs),
+        "heuristic_S12": lambda: gen_heuristic(16, 200, args.jobs, "S12", None, 300),
+        "heuristic_pool": lambda: gen_heuristic_pool(24, 120, args.jobs),
+        "heuristic_IRONCLAD": lambda: gen_heuristic(12, 120, args.jobs, "IRONCLAD", "SWARM", 400),
         "decks": gen_decks,
     }
     for name, fn in todo.items():

@@ -116,17 +116,26 @@ def test_expert_bot_vs_reference(engines, gold):
             assert sf[k] == 0 and hashes[k] == g["hash"][i], (k, t)
 
 
-def test_heuristic_selfplay_vs_reference(engines, gold):
+@pytest.mark.parametrize("fixture", ["trace_heuristic_N12M.npz", "trace_heuristic_S12.npz", "trace_heuristic_IRONCLAD.npz",
+                                     "trace_heuristic_pool.npz"])
+def test_heuristic_selfplay_vs_reference(engines, gold, fixture):
     """monsoon_decide against the reference's HeuristicAgent self-play (corrected loop): action,
-    complete score vector, best score and committed state at each of 2 400 decisions."""
-    g = gold("trace_heuristic_N12M.npz")
+    complete score vector, best score and committed state at every decision of the fixture's games (N12M mirror,
+    the Swarm deck, the reference's default Ironclad-vs-Swarm pair, per-game random decks); a game that the reference
+    ends with an exception (hash 0) faults here at the same decision."""
+    g = gold(fixture)
     n = len(g["seeds"])
-    eng = engines(16)
-    eng.reset(g["seeds"], np.stack([g["deck"], g["deck"]]))
+    if "decks" in g.files:
+        decks = g["decks"]                       # a pair of 12-card decks per game
+    else:
+        decks = np.stack([g["deck"], g["deck1"] if "deck1" in g.files else g["deck"]])
+    eng = engines(32)
+    eng.reset(g["seeds"], decks)
     off = g["offsets"]
     for t in range(int(g["max_turns"])):
         action, best, scores = eng.decide(g["w0"], want_scores=True)
         hashes = eng.state_hash()
+        faults = eng.game_faults()
         for k in range(n):
             i = off[k] + t
             if i >= off[k + 1]:
@@ -136,7 +145,10 @@ def test_heuristic_selfplay_vs_reference(engines, gold):
             assert int(legal.sum()) == g["nlegal"][i]
             assert oracle_lib.fnv1a64(scores[k][legal].tobytes()) == int(g["shash"][i]), (k, t)
             assert best[k] == g["best"][i]
-            assert hashes[k] == g["hash"][i], (k, t)
+            if int(g["hash"][i]) == 0:
+                assert faults[k] != 0, (k, t)
+            else:
+                assert faults[k] == 0 and hashes[k] == g["hash"][i], (k, t)
 
 
 @pytest.mark.parametrize("lanes", [16, 32, 64])

@@ -139,15 +139,28 @@ def test_set_iteration_order_known_answers(oracle_mod):
         assert list(out[:m]) == exp
 
 
-def test_heuristic_selfplay_trace(oracle_mod, gold):
+HEURISTIC_FIXTURES = ["trace_heuristic_N12M.npz", "trace_heuristic_S12.npz", "trace_heuristic_IRONCLAD.npz", "trace_heuristic_pool.npz"]
+
+
+@pytest.mark.parametrize("fixture", HEURISTIC_FIXTURES)
+def test_heuristic_selfplay_trace(oracle_mod, gold, fixture):
     """Corrected rollout loop vs the reference's HeuristicAgent: every decision's chosen action,
-    full score vector (hashed), best score and committed state."""
-    g = gold("trace_heuristic_N12M.npz")
+    full score vector (hashed), best score and committed state -- N12M mirror, the Swarm deck S12 (short games,
+    s203's set iteration), the reference's default Ironclad-vs-Swarm pair, and per-game random 12-card decks, where
+    look-aheads that raise (score 0.0) and committed steps that raise are common.  A game whose committed step raises
+    in the reference (hash 0 in the fixture) must fault here at the same decision."""
+    g = gold(fixture)
     orc = oracle_mod.Oracle(1)
-    deck, w = g["deck"], g["w0"]
+    w = g["w0"]
+    faults = g["fault"] if "fault" in g.files else np.zeros(len(g["seeds"]), dtype=np.uint8)
     for k, seed in enumerate(g["seeds"]):
         lo, hi = int(g["offsets"][k]), int(g["offsets"][k + 1])
-        orc.reset(0, int(seed), deck, deck)
+        if "decks" in g.files:
+            deck, deck1 = g["decks"][k]
+        else:
+            deck = g["deck"]
+            deck1 = g["deck1"] if "deck1" in g.files else deck
+        orc.reset(0, int(seed), deck, deck1)
         for t in range(lo, hi):
             a, scores, _ = orc.decide(0, w)
             legal = ~np.isnan(scores)
@@ -155,14 +168,20 @@ def test_heuristic_selfplay_trace(oracle_mod, gold):
             assert int(legal.sum()) == g["nlegal"][t]
             assert oracle_lib.fnv1a64(scores[legal].tobytes()) == int(g["shash"][t]), (k, t)
             assert scores[a] == g["best"][t]
-            orc.step(0, a)
-            assert orc.canon_hash(0) == int(g["hash"][t]), (k, t)
+            f = orc.step(0, a)[0]
+            if int(g["hash"][t]) == 0:
+                assert faults[k] and t == hi - 1 and f != 0, (k, t)
+            else:
+                assert f == 0 and orc.canon_hash(0) == int(g["hash"][t]), (k, t)
         # and the packaged rollout agrees with the step-by-step one
-        orc.reset(0, int(seed), deck, deck)
+        orc.reset(0, int(seed), deck, deck1)
         r = orc.rollout(0, w, w, int(g["max_turns"]), trace=True)
         assert r["result"] == g["result"][k] and r["steps"] == hi - lo
         assert np.array_equal(r["actions"], g["action"][lo:hi])
-        assert np.array_equal(r["hashes"], g["hash"][lo:hi])
+        if not faults[k]:
+            assert np.array_equal(r["hashes"], g["hash"][lo:hi])
+        else:
+            assert r["fault"] != 0 and np.array_equal(r["hashes"][:-1], g["hash"][lo:hi - 1])
 
 
 def test_quirk_spell_lands_one_tile_late(oracle_mod):
