@@ -121,6 +121,24 @@ int decide(Game& g, const double* w, double* scores_out, int* n_legal_out, uint6
   return best;
 }
 
+// Fault code of every legal action's look-ahead step (0 = none, 255 = not legal): lets a test tell a look-ahead the
+// reference also rejects (FAULT_PY_EXCEPTION, score 0.0) from one this build flags as unsupported (FAULT_UNSUPPORTED).
+void lookahead_faults(Game& g, uint8_t* out156) {
+  Engine<FlatMem> e = engine(g);
+  uint64_t mask[3];
+  e.legal_mask(mask);
+  for (int a = 0; a < 156; a++) {
+    out156[a] = 255;
+    if (!(mask[a >> 6] >> (a & 63) & 1)) continue;
+    Game c = g;
+    Engine<FlatMem> ce = engine(c);
+    ce.step(a);
+    int f = ce.fault();
+    if (!f && ce.observation_raises()) f = FAULT_INT_CARD;
+    out156[a] = (uint8_t)f;
+  }
+}
+
 // adapter = adapter.apply_action(action): commit.  Returns the fault code of the step.
 int commit(Game& g, int action) {
   Engine<FlatMem> e = engine(g);
@@ -233,6 +251,8 @@ int orc_have_winner(void* h, int gi) {
 int orc_to_play(void* h, int gi) { return ((Oracle*)h)->games[gi].st[H_TOPLAY]; }
 
 // scores156: NaN for illegal actions.  Returns the chosen action.
+void orc_lookahead_faults(void* h, int gi, uint8_t* out156) { lookahead_faults(((Oracle*)h)->games[gi], out156); }
+
 int orc_decide(void* h, int gi, const double* w10, double* scores156, uint64_t* mask3) {
   Game& g = ((Oracle*)h)->games[gi];
   int n;

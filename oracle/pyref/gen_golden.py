@@ -284,10 +284,10 @@ def gen_heuristic(n_games, max_turns, jobs, deck0="N12M", deck1=None, seed0=0):
           "ended by an exception", int(np.sum(out["fault"])))
 
 
-def gen_heuristic_pool(n_games, max_turns, jobs, seed0=700):
+def gen_heuristic_pool(n_games, max_turns, jobs, seed0=700, ext=False):
     """Heuristic self-play on per-game random 12-card decks (standard-build pool): look-aheads and committed steps
     that raise in the reference are common here (evo/heuristic_agent.py:48-51 -> score 0.0, evo/fitness.py:208-210)."""
-    pool = [c for c in H.CARD_IDS if c not in ("ua20", "b005", "up01", "up02", "up03")]
+    pool = [c for c in H.CARD_IDS if c not in (("up01", "up02", "up03") if ext else ("ua20", "b005", "up01", "up02", "up03"))]
     tasks, decks = [], []
     for s in range(n_games):
         rs = np.random.RandomState((seed0 + s) ^ 0x9E3779B9)
@@ -306,13 +306,13 @@ def gen_heuristic_pool(n_games, max_turns, jobs, seed0=700):
             out[k] += rec[k]
         out["offsets"].append(len(out["action"]))
     np.savez_compressed(
-        os.path.join(GOLD, "trace_heuristic_pool.npz"), seeds=np.array(out["seeds"], dtype=np.uint32),
+        os.path.join(GOLD, "trace_heuristic_pool_ext.npz" if ext else "trace_heuristic_pool.npz"), seeds=np.array(out["seeds"], dtype=np.uint32),
         offsets=np.array(out["offsets"], dtype=np.int64), result=np.array(out["result"], dtype=np.int8),
         fault=np.array(out["fault"], dtype=np.uint8),
         action=np.array(out["action"], dtype=np.uint8), hash=np.array(out["hash"], dtype=np.uint64),
         best=np.array(out["best"], dtype=np.float64), shash=np.array(out["shash"], dtype=np.uint64),
         nlegal=np.array(out["nlegal"], dtype=np.int16), decks=np.array(decks, dtype=np.uint8), w0=W0, max_turns=np.int32(max_turns))
-    print("trace_heuristic_pool.npz games", n_games, "decisions", len(out["action"]), "look-ahead steps", int(np.sum(out["nlegal"])),
+    print("trace_heuristic_pool_ext.npz" if ext else "trace_heuristic_pool.npz", "games", n_games, "decisions", len(out["action"]), "look-ahead steps", int(np.sum(out["nlegal"])),
           "ended by an exception", int(np.sum(out["fault"])))
 
 
@@ -403,6 +403,7 @@ def main():
         "heuristic": lambda: gen_heuristic(12, 200, args.jobs),
         "heuristic_S12": lambda: gen_heuristic(16, 200, args.jobs, "S12", None, 300),
         "heuristic_pool": lambda: gen_heuristic_pool(24, 120, args.jobs),
+        "heuristic_pool_ext": lambda: gen_heuristic_pool(16, 120, args.jobs, 900, ext=True),
         "heuristic_IRONCLAD": lambda: gen_heuristic(12, 120, args.jobs, "IRONCLAD", "SWARM", 400),
         "decks": gen_decks,
     }

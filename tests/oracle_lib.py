@@ -44,6 +44,8 @@ def lib(extended=False):
         L.orc_have_winner.argtypes = [ctypes.c_void_p, ctypes.c_int]
         L.orc_to_play.argtypes = [ctypes.c_void_p, ctypes.c_int]
         L.orc_decide.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+        L.orc_lookahead_faults.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
+        L.orc_lookahead_faults.restype = None
         L.orc_rollout.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p,
                                   ctypes.c_void_p, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_uint64),
                                   ctypes.POINTER(ctypes.c_int)]
@@ -144,6 +146,12 @@ class Oracle:
         mask = np.zeros(3, dtype=np.uint64)
         a = self.L.orc_decide(self.h, i, _p(w), _p(scores), _p(mask))
         return a, scores, mask
+
+    def lookahead_faults(self, i):
+        """Fault code of each legal action's look-ahead (255 = not legal); 20 = flagged as unsupported by this build."""
+        out = np.zeros(156, dtype=np.uint8)
+        self.L.orc_lookahead_faults(self.h, i, _p(out))
+        return out
 
     def rollout(self, i, w1, w2, max_turns, trace=False):
         w1 = np.ascontiguousarray(w1, dtype=np.float64)

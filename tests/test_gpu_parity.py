@@ -117,7 +117,7 @@ def test_expert_bot_vs_reference(engines, gold):
 
 
 @pytest.mark.parametrize("fixture", ["trace_heuristic_N12M.npz", "trace_heuristic_S12.npz", "trace_heuristic_IRONCLAD.npz",
-                                     "trace_heuristic_pool.npz"])
+                                     "trace_heuristic_pool.npz", "trace_heuristic_pool_ext.npz"])
 def test_heuristic_selfplay_vs_reference(engines, gold, fixture):
     """monsoon_decide against the reference's HeuristicAgent self-play (corrected loop): action,
     complete score vector, best score and committed state at every decision of the fixture's games (N12M mirror,
@@ -129,17 +129,31 @@ def test_heuristic_selfplay_vs_reference(engines, gold, fixture):
         decks = g["decks"]                       # a pair of 12-card decks per game
     else:
         decks = np.stack([g["deck"], g["deck1"] if "deck1" in g.files else g["deck"]])
-    eng = engines(32)
+    ext = fixture.endswith("_ext.npz")
+    eng = engines(32, extended=ext)
     eng.reset(g["seeds"], decks)
     off = g["offsets"]
+    # the CPU replay runs alongside only to detect the one flagged behaviour (a look-ahead restoring a nested b005
+    # memory): from that decision on a game is outside what this build reproduces
+    orc = oracle_lib.Oracle(n, extended=True) if ext else None
+    if ext:
+        for k in range(n):
+            orc.reset(k, int(g["seeds"][k]), decks[k][0], decks[k][1])
+    flagged = np.zeros(n, dtype=bool)
     for t in range(int(g["max_turns"])):
+        if ext:
+            for k in range(n):
+                if not flagged[k] and off[k] + t < off[k + 1] and (orc.lookahead_faults(k) == 20).any():
+                    flagged[k] = True
         action, best, scores = eng.decide(g["w0"], want_scores=True)
         hashes = eng.state_hash()
         faults = eng.game_faults()
         for k in range(n):
             i = off[k] + t
-            if i >= off[k + 1]:
+            if i >= off[k + 1] or flagged[k]:
                 continue
+            if ext:
+                orc.step(k, int(g["action"][i]))
             assert action[k] == g["action"][i], (k, t)
             legal = ~np.isnan(scores[k])
             assert int(legal.sum()) == g["nlegal"][i]
