@@ -218,7 +218,8 @@ def gen_pool(n_games, steps, jobs, ext=False):
 # ---------------------------------------------------------------------------------------------
 def heuristic_trace(args):
     """Corrected rollout loop: while not have_winner() and steps < max_turns."""
-    seed, d0, d1, max_turns = args
+    seed, d0, d1, max_turns = args[:4]
+    w_second = args[4] if len(args) > 4 else None   # a different weight vector for the SECOND player's agent
     from evo.game_adapter import StormboundAdapter
     from evo.heuristic_agent import HeuristicAgent
     from evo.weights import WeightVector
@@ -228,7 +229,11 @@ def heuristic_trace(args):
     game.env = H.make_game(seed, d0, d1)
     wv = WeightVector(10)
     wv.weights = W0.copy()
-    agents = [HeuristicAgent(wv, 0), HeuristicAgent(wv, 1)]
+    wv1 = wv
+    if w_second is not None:
+        wv1 = WeightVector(10)
+        wv1.weights = np.array(w_second, dtype=np.float64)
+    agents = [HeuristicAgent(wv, 0), HeuristicAgent(wv1, 1)]
     adapter = StormboundAdapter(game)
     rec = dict(action=[], hash=[], best=[], shash=[], nlegal=[])
     steps = 0
@@ -259,9 +264,10 @@ def heuristic_trace(args):
     return seed, rec, result, fault
 
 
-def gen_heuristic(n_games, max_turns, jobs, deck0="N12M", deck1=None, seed0=0):
+def gen_heuristic(n_games, max_turns, jobs, deck0="N12M", deck1=None, seed0=0, two_weights=False):
     d0, d1 = H.DECKS[deck0], H.DECKS[deck1 or deck0]
-    tasks = [(seed0 + s, d0, d1, max_turns) for s in range(n_games)]
+    w1 = np.random.RandomState(7).uniform(0, 1, 10) if two_weights else None
+    tasks = [(seed0 + s, d0, d1, max_turns) + ((w1,) if two_weights else ()) for s in range(n_games)]
     with ProcessPoolExecutor(jobs) as ex:
         results = list(ex.map(heuristic_trace, tasks))
     out = dict(seeds=[], offsets=[0], result=[], fault=[], action=[], hash=[], best=[], shash=[], nlegal=[])
@@ -272,14 +278,15 @@ def gen_heuristic(n_games, max_turns, jobs, deck0="N12M", deck1=None, seed0=0):
         for k in ("action", "hash", "best", "shash", "nlegal"):
             out[k] += rec[k]
         out["offsets"].append(len(out["action"]))
-    name = f"trace_heuristic_{deck0}.npz"
+    name = f"trace_heuristic_{deck0}{'_2w' if two_weights else ''}.npz"
     np.savez_compressed(
         os.path.join(GOLD, name), seeds=np.array(out["seeds"], dtype=np.uint32),
         offsets=np.array(out["offsets"], dtype=np.int64), result=np.array(out["result"], dtype=np.int8),
         fault=np.array(out["fault"], dtype=np.uint8),
         action=np.array(out["action"], dtype=np.uint8), hash=np.array(out["hash"], dtype=np.uint64),
         best=np.array(out["best"], dtype=np.float64), shash=np.array(out["shash"], dtype=np.uint64),
-        nlegal=np.array(out["nlegal"], dtype=np.int16), deck=idx(d0), deck1=idx(d1), w0=W0, max_turns=np.int32(max_turns))
+        nlegal=np.array(out["nlegal"], dtype=np.int16), deck=idx(d0), deck1=idx(d1), w0=W0,
+        w1=(w1 if two_weights else W0), max_turns=np.int32(max_turns))
     print(name, "games", n_games, "decisions", len(out["action"]), "look-ahead steps", int(np.sum(out["nlegal"])),
           "ended by an exception", int(np.sum(out["fault"])))
 
@@ -401,6 +408,7 @@ def main():
         "random_S12": lambda: gen_random("S12", None, 48, 300, args.jobs),
         "expert": lambda: gen_expert(48, 300, args.jobs),
         "heuristic": lambda: gen_heuristic(12, 200, args.jobs),
+        "heuristic_2w": lambda: gen_heuristic(8, 150, args.jobs, "N12M", None, 1200, two_weights=True),
         "heuristic_S12": lambda: gen_heuristic(16, 200, args.jobs, "S12", None, 300),
         "heuristic_pool": lambda: gen_heuristic_pool(24, 120, args.jobs),
         "heuristic_pool_ext": lambda: gen_heuristic_pool(16, 120, args.jobs, 900, ext=True),

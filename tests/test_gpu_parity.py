@@ -165,6 +165,28 @@ def test_heuristic_selfplay_vs_reference(engines, gold, fixture):
                 assert faults[k] == 0 and hashes[k] == g["hash"][i], (k, t)
 
 
+def test_heuristic_two_weight_vectors_vs_reference(engines, gold):
+    """Per-side weight vectors [n][2][10]: the kernel uses the mover's vector as the reference's
+    agents[adapter.get_current_player()] does -- action, score vector, best score, committed state of every decision."""
+    g = gold("trace_heuristic_N12M_2w.npz")
+    n = len(g["seeds"])
+    eng = engines(16)
+    eng.reset(g["seeds"], np.stack([g["deck"], g["deck1"]]))
+    w = np.broadcast_to(np.stack([g["w0"], g["w1"]]), (n, 2, 10)).copy()
+    off = g["offsets"]
+    for t in range(int(g["max_turns"])):
+        action, best, scores = eng.decide(w, want_scores=True)
+        hashes = eng.state_hash()
+        for k in range(n):
+            i = off[k] + t
+            if i >= off[k + 1]:
+                continue
+            assert action[k] == g["action"][i], (k, t)
+            legal = ~np.isnan(scores[k])
+            assert oracle_lib.fnv1a64(scores[k][legal].tobytes()) == int(g["shash"][i]), (k, t)
+            assert best[k] == g["best"][i] and hashes[k] == g["hash"][i], (k, t)
+
+
 @pytest.mark.parametrize("lanes", [16, 32, 64])
 def test_rollout_vs_oracle_2048_games(engines, lanes):
     """All lane configurations (16 forces the multi-pass + replay path) give the oracle's games."""

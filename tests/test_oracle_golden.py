@@ -194,6 +194,21 @@ def test_heuristic_selfplay_trace(oracle_mod, gold, fixture):
             assert r["fault"] != 0 and np.array_equal(r["hashes"][:-1], g["hash"][lo:hi - 1])
 
 
+def test_heuristic_selfplay_two_weight_vectors(oracle_mod, gold):
+    """Different weights for the two agents (reference: agents[adapter.get_current_player()]): the packaged rollout
+    picks the mover's vector exactly as the reference does -- actions and committed states of 1 200 decisions."""
+    g = gold("trace_heuristic_N12M_2w.npz")
+    orc = oracle_mod.Oracle(1)
+    assert not np.array_equal(g["w0"], g["w1"])
+    for k, seed in enumerate(g["seeds"]):
+        lo, hi = int(g["offsets"][k]), int(g["offsets"][k + 1])
+        orc.reset(0, int(seed), g["deck"], g["deck1"])
+        r = orc.rollout(0, g["w0"], g["w1"], int(g["max_turns"]), trace=True)
+        assert r["result"] == g["result"][k] and r["steps"] == hi - lo
+        assert np.array_equal(r["actions"], g["action"][lo:hi])
+        assert np.array_equal(r["hashes"], g["hash"][lo:hi])
+
+
 def test_quirk_spell_lands_one_tile_late(oracle_mod):
     """USE action 65+21c+tile executes at tile+1; the last tile is a no-op that
     costs nothing.  Checked as properties of the restatement on a constructed position."""
