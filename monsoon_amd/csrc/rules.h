@@ -23,7 +23,9 @@ struct P {
 MSB_HD MSB_INL bool p_valid(P p) { return p.x >= 0 && p.x <= 3 && p.y >= 0 && p.y <= 4; }        // point.py:15-17
 MSB_HD MSB_INL bool p_is_base(P p) { return p.x == -1 && (p.y == -1 || p.y == 5); }              // point.py:19-21
 MSB_HD MSB_INL bool p_eq(P a, P b) { return a.x == b.x && a.y == b.y; }
-MSB_HD MSB_INL int p_pack(P p) { return ((p.y + 1) << 3) | (p.x + 1); }                          // x in [-1,6], y in [-1,5]
+// x in [-1,6], y in [-1,5]; points further out (a path running on past a base) only ever get compared, never decoded --
+// unsigned arithmetic keeps the shift of their negative row defined
+MSB_HD MSB_INL int p_pack(P p) { return (int)(((unsigned)(p.y + 1) << 3) | (unsigned)(p.x + 1)); }
 MSB_HD MSB_INL P p_unpack(int v) { return P{(v & 7) - 1, (v >> 3) - 1}; }
 MSB_HD MSB_INL int p_tile(P p) { return p.y * 4 + p.x; }
 MSB_HD MSB_INL P tile_p(int t) { return P{t & 3, t >> 2}; }
