@@ -345,6 +345,31 @@ def test_observation_tensor_view_on_device(engines):
     assert np.array_equal(dev.cpu().numpy(), host) and np.array_equal(draises.cpu().numpy(), raises)
 
 
+def test_rollout_rejects_empty_and_out_of_range_schedules(engines):
+    """Empty schedule, a match naming a missing deck or individual, a ragged deck array: refused with an error, no
+    game is played (the reference would raise IndexError / produce nothing)."""
+    from monsoon_amd import MonsoonError
+    eng = engines(64)
+    deck = deck_indices("N12M")
+    pairs = np.stack([deck, deck])[None]
+    dt = [("p1", "<i4"), ("p2", "<i4"), ("seed", "<u4"), ("deck", "<u4")]
+    with pytest.raises(MonsoonError):
+        eng.rollout(W0[None], np.zeros(0, dtype=dt), pairs, 10)
+    m = np.zeros(4, dtype=dt)
+    m["deck"][2] = 1                      # only deck 0 exists
+    with pytest.raises(MonsoonError):
+        eng.rollout(W0[None], m, pairs, 10)
+    m = np.zeros(4, dtype=dt)
+    m["p2"][1] = 3                        # only individual 0 exists
+    with pytest.raises(MonsoonError):
+        eng.rollout(W0[None], m, pairs, 10)
+    with pytest.raises(ValueError):
+        eng.rollout(W0[None], np.zeros(4, dtype=dt), np.zeros((1, 2, 11), dtype=np.uint8), 10)
+    # and a well-formed call still works on the same handle afterwards
+    counts = eng.rollout(W0[None], np.zeros(4, dtype=dt), pairs, 5)
+    assert counts[0, 2] == 4
+
+
 def test_game_view_and_error_behaviour(engines):
     from monsoon_amd import MonsoonError
     from monsoon_amd.engine import BatchEngine
