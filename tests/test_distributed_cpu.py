@@ -26,6 +26,13 @@ def _population():
     return [WeightVector(10) for _ in range(4)]
 
 
+def _deck_schedule():
+    from monsoon_amd.cards import DECKS
+    from monsoon_amd.decks import DeckEvolutionConfig
+    # generation 3 is in the explore phase: a different deck pair per game, drawn from one seeded stream
+    return DeckEvolutionConfig(DECKS["IRONCLAD"], DECKS["SWARM"], exploit_generations=1, explore_generations=4, seed=9)
+
+
 def _worker(rank, world, port, out_dir):
     import sys
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
@@ -37,6 +44,10 @@ def _worker(rank, world, port, out_dir):
     ev = FitnessEvaluator(cfg, rollout_fn=oracle_rollout_fn)
     f = ev.evaluate_population(_population(), generation=3)
     np.save(os.path.join(out_dir, f"fit{rank}.npy"), np.array(f))
+    # with a deck schedule every rank draws the decks of the WHOLE schedule and keeps its shard's
+    ev2 = FitnessEvaluator(cfg, _deck_schedule(), rollout_fn=oracle_rollout_fn)
+    f2 = ev2.evaluate_population(_population(), generation=3)
+    np.save(os.path.join(out_dir, f"fitdeck{rank}.npy"), np.array(f2))
     dist.destroy_process_group()
 
 
@@ -50,3 +61,8 @@ def test_sharded_evaluation_matches_single_process(tmp_path):
     single = FitnessEvaluator(cfg, rollout_fn=oracle_rollout_fn).evaluate_population(_population(), generation=3)
     assert np.array_equal(f0, f1)
     assert np.array_equal(f0, np.array(single))
+    d0 = np.load(tmp_path / "fitdeck0.npy")
+    d1 = np.load(tmp_path / "fitdeck1.npy")
+    single_deck = FitnessEvaluator(cfg, _deck_schedule(), rollout_fn=oracle_rollout_fn).evaluate_population(_population(), generation=3)
+    assert np.array_equal(d0, d1)
+    assert np.array_equal(d0, np.array(single_deck))
