@@ -682,13 +682,27 @@ __global__ void k_count_live(DevBuffers b, int n, int* live) {
 
 __global__ void k_collect(DevBuffers b, int n, int32_t* counts, int8_t* results, int32_t* steps) {
   int g = blockIdx.x * blockDim.x + threadIdx.x;
-  if (g >= n) return;
-  GameMeta m = b.meta[g];
+  const bool on = g < n;
+  GameMeta m = b.meta[on ? g : 0];
   int r = m.result == -2 ? -1 : m.result;
-  // evo/fitness.py:160-166: wins + 0.5*draws for the row individual (p1)
-  if (r == 0) atomicAdd(&counts[3 * m.p1 + 0], 1);
-  if (r == -1) atomicAdd(&counts[3 * m.p1 + 1], 1);
-  atomicAdd(&counts[3 * m.p1 + 2], 1);
+  // evo/fitness.py:160-166: wins + 0.5*draws for the row individual (p1).  Consecutive games usually share their row
+  // individual: the lanes of a wave are grouped by p1 and one lane adds the group's totals (an atomicAdd per game on
+  // the same address serialises at ~25 ns each).
+  const int lane = threadIdx.x & 63;
+  for (unsigned long long todo = __ballot(on); todo;) {
+    const int leader = __builtin_ctzll(todo);
+    const int key = __builtin_amdgcn_readlane(m.p1, leader);
+    const bool mine = on && m.p1 == key;
+    const unsigned long long grp = __ballot(mine);
+    const int wins = __popcll(__ballot(mine && r == 0)), draws = __popcll(__ballot(mine && r == -1));
+    if (lane == leader) {
+      if (wins) atomicAdd(&counts[3 * key + 0], wins);
+      if (draws) atomicAdd(&counts[3 * key + 1], draws);
+      atomicAdd(&counts[3 * key + 2], __popcll(grp));
+    }
+    todo &= ~grp;
+  }
+  if (!on) return;
   if (results) results[m.match] = (int8_t)r;
   if (steps) steps[m.match] = m.steps;
 }
