@@ -164,3 +164,18 @@ def test_evaluator_draws_a_deck_pair_per_game_from_the_schedule():
     assert p2.shape == (12, 2, 12) and np.array_equal(d2, np.arange(12))
     assert len({p2[k].tobytes() for k in range(12)}) > 1            # explore phase: the games differ
     assert np.array_equal(seen[3][1], p2)                          # same seed, same schedule
+
+
+def test_every_card_with_an_ability_has_a_case():
+    """ability_cases.inc (one function per card) against the card table generated from the reference's constructors:
+    every unit/structure that overrides activate_ability and every spell has exactly one entry, nothing else has."""
+    import json
+    import re
+    root = os.path.join(os.path.dirname(__file__), "..", "monsoon_amd")
+    cases = open(os.path.join(root, "csrc", "ability_cases.inc")).read()
+    entity = [m.lower()[2:] for m in re.findall(r"MSB_CARD\((C_\w+),", cases)]
+    spells = [m.lower()[2:] for m in re.findall(r"MSB_SPELL\((C_\w+),", cases)]
+    meta = json.load(open(os.path.join(root, "card_ids.json")))
+    assert sorted(entity) == sorted(c["id"] for c in meta if c["kind"] != 2 and c["has_ability"])
+    assert sorted(spells) == sorted(c["id"] for c in meta if c["kind"] == 2)
+    assert len(set(entity)) == len(entity) and len(set(spells)) == len(spells)
