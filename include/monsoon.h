@@ -36,7 +36,8 @@ typedef struct monsoon monsoon_t;
 typedef struct {
   int32_t device;          /* HIP device ordinal */
   int32_t max_games;       /* capacity of the batch */
-  int32_t lanes_per_game;  /* candidate successor states resident per wavefront: 8, 16, 32 or 64 (0 = default 8) */
+  int32_t lanes_per_game;  /* candidate lanes (successor states stepped at once) per game: 4, 8, 16, 32 or 64; 0 = default.
+                              Must be a kernel variant of the build (monsoon_amd/csrc/variants.def), else create fails */
   int32_t stack_bytes;     /* per-lane scratch stack for the rules core's recursion (0 = default) */
 } monsoon_config;
 
@@ -54,12 +55,16 @@ typedef struct {
   uint64_t games_finished;   /* games that ended with a winner */
   uint64_t faults;           /* games stopped by a fault (reference: swallowed exception -> draw) */
   uint64_t capacity_faults;  /* of those, build-limit faults (must be 0 for a valid run) */
+  uint64_t lookahead_capacity_faults;  /* games in which a LOOK-AHEAD hit a build limit: that action scored 0.0 where the
+                                          reference computes a score (must be 0 for a valid run) */
 } monsoon_stats;
 
 int monsoon_create(const monsoon_config* cfg, monsoon_t** out);
 void monsoon_destroy(monsoon_t* h);
 const char* monsoon_last_error(monsoon_t* h);   /* h may be NULL: last create() error */
 int monsoon_version(void);
+/* the hot-kernel variant the handle runs (any pointer may be NULL) */
+int monsoon_variant(monsoon_t* h, int32_t* lanes_per_game, int32_t* waves_per_simd);
 /* card id string ("u007") -> table index used in deck arrays; -1 if unknown.  card.py:15 */
 int monsoon_card_index(const char* card_id);
 /* 1 if the card's ability is implemented by this build (decks with other cards are refused) */
@@ -73,7 +78,8 @@ int monsoon_reset(monsoon_t* h, int32_t n, const uint32_t* seeds, const uint8_t*
 int monsoon_legal_mask(monsoon_t* h, uint64_t* out);
 
 /* Stormbound.step (games/stormbound.py:318-373) for every game; actions[n] must be legal
- * (PASS = 155 is always accepted, as the reference's scripted bot relies on; actions[i] = 255 leaves game i untouched).  reward[n] in {0,1}, done[n], fault[n] (0 = none). */
+ * (PASS = 155 is always accepted, as the reference's scripted bot relies on; actions[i] = 255 leaves game i untouched).
+ * An illegal entry refuses the whole call (MONSOON_ERR_ARG) before any game is stepped.  reward[n] in {0,1}, done[n], fault[n] (0 = none). */
 int monsoon_step(monsoon_t* h, const uint8_t* actions, int8_t* reward, uint8_t* done, uint8_t* fault);
 
 /* Stormbound.expert_action (games/stormbound.py:563-637), the reference's scripted opponent, for every game:
@@ -97,7 +103,7 @@ int monsoon_features(monsoon_t* h, double* out);
  * {to_play, have_winner, base_first, base_second}. */
 int monsoon_status(monsoon_t* h, int32_t* out);
 
-/* The fault code that stopped each loaded game (0 = none): out[n].  The reference's exceptions are swallowed by
+/* The fault code that stopped each loaded game, else the first build-limit code one of its look-aheads hit (0 = none): out[n].  The reference's exceptions are swallowed by
  * its agent layer (evo/heuristic_agent.py:48-51, evo/fitness.py:170-174,208-210); codes in msb_base.h, >= 16 are
  * limits of this build. */
 int monsoon_game_faults(monsoon_t* h, uint8_t* out);
@@ -105,6 +111,14 @@ int monsoon_game_faults(monsoon_t* h, uint8_t* out);
 /* Canonical state record of game idx (layout: monsoon_amd/csrc/canon.h), the comparand of the
  * bit-exactness tests.  buf must hold 1024 bytes. */
 int monsoon_state_export(monsoon_t* h, int32_t idx, uint8_t* buf, int32_t* len);
+
+/* copy.deepcopy(game) across the boundary (evo/game_adapter.py:280-287 clone_state): the COMPLETE device state of game
+ * idx -- record, bookkeeping row, numpy stream position -- as an opaque blob of monsoon_state_blob_bytes() bytes.
+ * monsoon_state_load puts a blob into slot idx of any handle of the same build (idx <= number of loaded games; idx ==
+ * that number appends a game, max_games permitting): the clone then continues bit-identically to the original. */
+int32_t monsoon_state_blob_bytes(void);
+int monsoon_state_save(monsoon_t* h, int32_t idx, uint8_t* buf, int32_t buf_bytes);
+int monsoon_state_load(monsoon_t* h, int32_t idx, const uint8_t* buf, int32_t buf_bytes);
 
 /* Debugging aid: the raw HBM record of game idx (monsoon_amd/csrc/state.h layout); buf must hold 4096 bytes. */
 int monsoon_debug_raw(monsoon_t* h, int32_t idx, uint8_t* buf, int32_t* len);
@@ -141,6 +155,9 @@ int monsoon_debug_counters(monsoon_t* h, unsigned long long* out192);
 int monsoon_upload_weights(monsoon_t* h, const double* weights, int32_t n_individuals);
 int monsoon_assign_players(monsoon_t* h, const int32_t* p1, const int32_t* p2);   /* [n] indices */
 int monsoon_decide_round_dev(monsoon_t* h);   /* asynchronous on the handle's stream */
+/* `rounds` decisions of every loaded game in one launch (evo/fitness.py:193-211, a slice of the _play_game loop): a
+ * game's record stays on chip from its first to its last decision of the call.  Asynchronous like the call above. */
+int monsoon_play_rounds_dev(monsoon_t* h, int32_t rounds);
 int monsoon_sync(monsoon_t* h);
 
 int monsoon_get_stats(monsoon_t* h, monsoon_stats* out);

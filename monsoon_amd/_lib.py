@@ -28,7 +28,7 @@ class Match(ctypes.Structure):
 
 class Stats(ctypes.Structure):
     _fields_ = [("lookahead_steps", ctypes.c_uint64), ("decisions", ctypes.c_uint64), ("games_finished", ctypes.c_uint64),
-                ("faults", ctypes.c_uint64), ("capacity_faults", ctypes.c_uint64)]
+                ("faults", ctypes.c_uint64), ("capacity_faults", ctypes.c_uint64), ("lookahead_capacity_faults", ctypes.c_uint64)]
 
 
 class MonsoonError(RuntimeError):
@@ -43,6 +43,10 @@ SIGNATURES = {
     "monsoon_destroy": (None, [ctypes.c_void_p]),
     "monsoon_last_error": (ctypes.c_char_p, [ctypes.c_void_p]),
     "monsoon_version": (ctypes.c_int, []),
+    "monsoon_variant": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int32)]),
+    "monsoon_state_blob_bytes": (ctypes.c_int32, []),
+    "monsoon_state_save": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p, ctypes.c_int32]),
+    "monsoon_state_load": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p, ctypes.c_int32]),
     "monsoon_card_index": (ctypes.c_int, [ctypes.c_char_p]),
     "monsoon_card_supported": (ctypes.c_int, [ctypes.c_int]),
     "monsoon_reset": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
@@ -64,6 +68,7 @@ SIGNATURES = {
     "monsoon_upload_weights": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32]),
     "monsoon_assign_players": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
     "monsoon_decide_round_dev": (ctypes.c_int, [ctypes.c_void_p]),
+    "monsoon_play_rounds_dev": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32]),
     "monsoon_sync": (ctypes.c_int, [ctypes.c_void_p]),
     "monsoon_get_stats": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(Stats)]),
     "monsoon_debug_counters": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p]),

@@ -43,7 +43,7 @@ class EvolutionaryConfig:
     games_per_individual: int = 64   # ring schedule only
     deck: str = "N12M"               # key of monsoon_amd.cards.DECKS, both sides
     max_concurrent_games: int = 65536
-    lanes_per_game: int = 0
+    lanes_per_game: int = 0          # hot-kernel variant: candidate lanes per game (0 = build default)
 
     # nested-JSON sections of the reference's configs/config.json -> flat fields
     _SECTIONS = {

@@ -1,23 +1,8 @@
-// libmonsoon_hip.so -- MI355X (gfx950) batched Stormbound engine: kernels + C ABI (include/monsoon.h).
+// libmonsoon_hip.so -- MI355X (gfx950) batched Stormbound engine: API kernels + C ABI (include/monsoon.h).
 //
-// Execution model
-//   * Hot kernel k_decide<U>: ONE WAVEFRONT PER GAME (a persistent grid of resident wavefronts, each popping game
-//     indices from its range's counter).  The game's record (992 B) is staged from HBM into LDS with one coalesced
-//     pass; the legal-action mask is evaluated on that shared copy (LDS broadcast reads), the "before" features
-//     are the ones the previous decision computed for the successor it committed; then up to U candidate actions
-//     are advanced at once, lane l stepping its own private copy of the state.  The private copies are interleaved
-//     across lanes in 16-byte granules (granule c of lane l at (c*U + l)*16), so lanes touching the same field hit
-//     distinct LDS banks and a whole entity is one ds_read_b128.  Scores are reduced with shuffles over the U
-//     candidate lanes (first maximum in ascending action order = np.argmax over the sorted legal list) and the
-//     winner's column is written back as the game's new record.  Nothing is re-executed: the committed successor
-//     IS one of the look-ahead results (when the legal set needs several passes of U lanes, the best successor so
-//     far is parked in a spare LDS column).
-//   * The game's MT19937 stream lives in HBM as two blocks of tempered outputs (current + next)
-//     plus the raw state; candidate steps read it through a private cursor, the committed
-//     cursor is stored back and the wave regenerates a block (twist in LDS) when it is used up.
-//   * API kernels (reset/step/legal/observe/features/status/export) map one LANE per game with the
-//     same LDS layout (U = 64); they back the batch=1 Game view and the parity tests.
-//   * Integer/index work: no MFMA.  f64 appears only in the weighted draw and the score.
+// The hot kernel (k_play, kernels.h) is compiled one variant per translation unit (variant.hip); this
+// file holds the lane-per-game API kernels (reset/step/legal/observe/features/status/export: one LANE per game with
+// the same lane-interleaved LDS layout; they back the batch=1 Game view and the parity tests) and the host side.
 //
 // There is no CPU path in this library.  A missing/unsupported device is an error.
 #include <hip/hip_runtime.h>
@@ -31,155 +16,12 @@
 #include <string>
 #include <vector>
 
-#include "../../include/monsoon.h"
-#include "canon.h"
+#include "kernels.h"
 
 using namespace msb;
+using namespace msbk;
 
 namespace {
-
-constexpr int SW = STATE_WORDS;               // record stride in HBM, words (STATE_BYTES is a multiple of 16)
-constexpr int SG = STATE_BYTES / 16;         // 16-byte granules per record
-static_assert(STATE_BYTES % 16 == 0, "record must be whole granules");
-typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-constexpr int RNG_WORDS = 2 * MT_N;          // tempered outputs: two blocks per game
-
-struct GameMeta {
-  int32_t p1, p2;          // weight-table rows of the FIRST / SECOND player
-  int8_t result;           // -2 running, -1 draw, 0 FIRST won, 1 SECOND won
-  uint8_t fault;
-  uint8_t last_action;
-  uint8_t flags;           // b0: ended with a winner (have_winner), as opposed to max_turns / a fault
-                           // b1: cfeat[last_action] holds the features of the CURRENT state (it was the committed successor)
-  uint16_t steps;          // committed steps (decisions and monsoon_step calls)
-  uint16_t decided;        // decisions committed by k_decide
-  uint32_t rng;            // cursor (bits 0-15) | current block (bit 16)
-  uint32_t lookahead;      // look-ahead transitions executed for this game
-  uint32_t match;          // schedule index (rollout)
-};
-
-struct DevBuffers {
-  uint32_t* state;     // [cap][SW]
-  uint32_t* rng_out;   // [cap][2][624]
-  uint32_t* rng_mt;    // [cap][624]
-  GameMeta* meta;      // [cap]
-  double* weights;     // [n_individuals][10]
-  unsigned long long* stats;  // [8]: lookahead, decisions, finished, faults, capacity_faults
-  double* scores;      // [cap][156] or null
-  double* best;        // [cap]
-  double* cfeat;       // [cap][156][10] features of every look-ahead successor of the last decision, by action id
-  int* pop;            // [2][POP_PARTS * POP_STRIDE] game-index counters of the persistent k_decide, alternating between launches
-  unsigned long long* prof;   // [cap][..] phase cycles, scope cycles, scope calls (profiling build), profiling build only (else null)
-};
-
-enum { ST_LOOKAHEAD = 0, ST_DECISIONS = 1, ST_FINISHED = 2, ST_FAULTS = 3, ST_CAPFAULTS = 4, ST_PROF = 8, ST_WORDS = 32, PROF_WORDS = 138 };
-// Phase timing of k_decide (profiling build only, -DMSB_PROF=1 -> libmonsoon_hip_prof.so; never the product):
-// wave cycles per phase accumulated into stats[ST_PROF + phase].
-#if defined(MSB_PROF) && MSB_PROF
-#define PROF_DECL()                                                                                   \
-  unsigned long long prof_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};                                          \
-  const unsigned long long prof_wall0 = wall_clock64();                                               \
-  for (int i_ = lane; i_ < (928 - 16) / 4; i_ += 64) *(MSB_AS_LDS unsigned*)(uintptr_t)(MSB_PROF_LDS + 4 * i_) = 0u; \
-  __syncthreads();                                                                                    \
-  unsigned long long prof_t = __builtin_readcyclecounter()
-#define PROF_MARK(ph)                                         \
-  do {                                                        \
-    unsigned long long now_ = __builtin_readcyclecounter();   \
-    prof_acc[ph] += now_ - prof_t;                            \
-    prof_t = now_;                                            \
-  } while (0)
-#define PROF_FLUSH()                                                        \
-  do {                                                                      \
-    __syncthreads();                                                        \
-    if (lane == 0)                                                          \
-      for (int i_ = 0; i_ < 8; i_++) b.prof[(size_t)g * PROF_WORDS + i_] += prof_acc[i_]; \
-    if (lane == 0) {                                                        \
-      b.prof[(size_t)g * PROF_WORDS + 136] = prof_wall0;                    \
-      b.prof[(size_t)g * PROF_WORDS + 137] = wall_clock64();                \
-    }                                                                       \
-    if (lane < 32) {                                                        \
-      b.prof[(size_t)g * PROF_WORDS + 8 + lane] += *(MSB_AS_LDS unsigned long long*)(uintptr_t)(MSB_PROF_LDS + 8 * lane); \
-      b.prof[(size_t)g * PROF_WORDS + 40 + lane] += *(MSB_AS_LDS unsigned*)(uintptr_t)(MSB_PROF_LDS + 256 + 4 * lane);   \
-      b.prof[(size_t)g * PROF_WORDS + 72 + lane] += *(MSB_AS_LDS unsigned long long*)(uintptr_t)(MSB_PROF_LDS + 384 + 8 * lane); \
-      b.prof[(size_t)g * PROF_WORDS + 104 + lane] += *(MSB_AS_LDS unsigned long long*)(uintptr_t)(MSB_PROF_LDS + 640 + 8 * lane); \
-    }                                                                       \
-  } while (0)
-#else
-#define PROF_DECL() do {} while (0)
-#define PROF_MARK(ph) do {} while (0)
-#define PROF_FLUSH() do {} while (0)
-#endif
-
-// ------------------------------------------------------------------------------------------------
-// RNG block maintenance (wave-cooperative, in LDS)
-// ------------------------------------------------------------------------------------------------
-// In-place MT19937 twist of 624 words in LDS by one wavefront.  Within one pass all lanes read
-// before any lane writes (a wave executes in lockstep), and passes are ordered by barriers.
-__device__ void wave_twist_lds(MSB_AS_LDS uint32_t* mt, int lane) {
-  for (int k0 = 0; k0 < MT_N - MT_M; k0 += 64) {
-    int k = k0 + lane;
-    uint32_t v = 0;
-    bool on = k < MT_N - MT_M;
-    if (on) v = mt[k + MT_M] ^ mt_mix(mt[k], mt[k + 1]);
-    __syncthreads();
-    if (on) mt[k] = v;
-    __syncthreads();
-  }
-  for (int k0 = MT_N - MT_M; k0 < MT_N - 1; k0 += 64) {
-    int k = k0 + lane;
-    uint32_t v = 0;
-    bool on = k < MT_N - 1;
-    if (on) v = mt[k + (MT_M - MT_N)] ^ mt_mix(mt[k], mt[k + 1]);
-    __syncthreads();
-    if (on) mt[k] = v;
-    __syncthreads();
-  }
-  if (lane == 0) mt[MT_N - 1] = mt[MT_M - 1] ^ mt_mix(mt[MT_N - 1], mt[0]);
-  __syncthreads();
-}
-
-// Regenerate tempered block `which` of game g from the raw state (advancing it one twist).
-__device__ void wave_refill(const DevBuffers& b, int g, int which, MSB_AS_LDS uint32_t* tmp, int lane) {
-  uint32_t* mt = b.rng_mt + (size_t)g * MT_N;
-  for (int k = lane; k < MT_N; k += 64) tmp[k] = mt[k];
-  __syncthreads();
-  wave_twist_lds(tmp, lane);
-  uint32_t* out = b.rng_out + (size_t)g * RNG_WORDS + which * MT_N;
-  for (int k = lane; k < MT_N; k += 64) {
-    uint32_t v = tmp[k];
-    mt[k] = v;
-    out[k] = mt_temper(v);
-  }
-  __syncthreads();
-}
-
-// Attach game g's stream window to the record an engine works on (fields H_RNGCUR/NXT/POS).
-template <class E>
-__device__ MSB_INL void attach_rng(E& e, const DevBuffers& b, int g, uint32_t rng) {
-  const uint32_t* base = b.rng_out + (size_t)g * RNG_WORDS;
-  int cur = (rng >> 16) & 1;
-  e.rng_attach(base + cur * MT_N, base + (cur ^ 1) * MT_N, rng & 0xffffu);
-}
-__device__ MSB_INL uint32_t peek_u32(const DevBuffers& b, int g, uint32_t rng) {
-  const uint32_t* base = b.rng_out + (size_t)g * RNG_WORDS;
-  int cur = (rng >> 16) & 1;
-  uint32_t pos = rng & 0xffffu;
-  return pos < (uint32_t)MT_N ? base[cur * MT_N + pos] : base[(cur ^ 1) * MT_N + pos - MT_N];
-}
-
-// Serial form for the lane-per-game API kernels: one lane owns the game.
-__device__ void lane_commit_rng(const DevBuffers& b, int g, GameMeta& m, uint32_t pos) {
-  int cur = (m.rng >> 16) & 1;
-  if (pos >= (uint32_t)MT_N) {
-    pos -= MT_N;
-    uint32_t* mt = b.rng_mt + (size_t)g * MT_N;
-    mt_twist(mt);
-    uint32_t* out = b.rng_out + (size_t)g * RNG_WORDS + cur * MT_N;
-    for (int k = 0; k < MT_N; k++) out[k] = mt_temper(mt[k]);
-    cur ^= 1;
-  }
-  m.rng = pos | ((uint32_t)cur << 16);
-}
 
 // ------------------------------------------------------------------------------------------------
 // Lane-per-game API kernels.  Block = 64 threads; the records are staged in DYNAMIC LDS starting at LDS
@@ -193,15 +35,11 @@ constexpr int API_LANES = 64;
 #endif
 // LDS address 0 is avoided on purpose: an integer constant 0 cast to an LDS pointer is the null pointer,
 // which is not address 0 on this target; every region starts at LDS_ORIGIN.
-#if defined(MSB_PROF) && MSB_PROF
-constexpr int LDS_ORIGIN = 928;   // [16,928): function-scope counters of the profiling build (msb_base.h)
-#else
-constexpr int LDS_ORIGIN = 16;
-#endif
 constexpr int API_LDS_BYTES = LDS_ORIGIN + SG * API_LANES * 16;
 typedef LaneMem<API_LANES, LDS_ORIGIN> ApiMem;
 typedef Engine<ApiMem> ApiEngine;
 #define API_GAME_INDEX()                                  \
+  lds_init_wtab();                                        \
   if ((int)threadIdx.x >= API_LANES) return;              \
   int g = blockIdx.x * API_LANES + threadIdx.x;           \
   if (g >= n) return;
@@ -298,7 +136,6 @@ __global__ void __launch_bounds__(64) k_step(DevBuffers b, int n, const uint8_t*
   lane_commit_rng(b, g, m, e.rng_pos());
   m.steps++;
   m.last_action = (uint8_t)a;
-  m.flags &= ~2;   // no cached features for a state reached through monsoon_step
   if (e.fault()) m.fault = (uint8_t)e.fault();
   b.meta[g] = m;
   api_store(b.state + (size_t)g * SW);
@@ -353,6 +190,7 @@ __global__ void __launch_bounds__(64) k_status(DevBuffers b, int n, int32_t* out
 }
 
 __global__ void __launch_bounds__(64) k_export(DevBuffers b, int g, uint8_t* out, int32_t* len) {
+  lds_init_wtab();
   if (threadIdx.x != 0) return;
   ApiEngine e;
   api_load(b.state + (size_t)g * SW);
@@ -368,279 +206,11 @@ __global__ void __launch_bounds__(64) k_hash(DevBuffers b, int n, uint64_t* out)
   out[g] = fnv1a64(rec, len);
 }
 
-// ------------------------------------------------------------------------------------------------
-// Hot kernel: one decision (look-ahead + score + argmax + commit) per game, one wavefront per game.
-// Dynamic LDS map (bytes):  [0, SG*U*16) candidate records, lane-interleaved | parent record | best
-// ------------------------------------------------------------------------------------------------
-__device__ MSB_INL int nth_set_bit(const uint64_t mask[3], int k) {
-  for (int w = 0; w < 3; w++) {
-    int c = __popcll(mask[w]);
-    if (k < c) {
-      uint64_t m = mask[w];
-      for (int i = 0; i < k; i++) m &= m - 1;
-      return w * 64 + __ffsll((long long)m) - 1;
-    }
-    k -= c;
-  }
-  return -1;
-}
-
-template <int U>
-struct DecideLds {
-  static constexpr int PRIV = LDS_ORIGIN;
-  static constexpr int PRIV_BYTES = SG * U * 16 > MT_N * 4 ? SG * U * 16 : ((MT_N * 4 + 15) & ~15);   // doubles as the twist buffer
-  static constexpr int PAR = PRIV + PRIV_BYTES;
-  static constexpr int BEST = PAR + SG * 16;
-  static constexpr int WF = BEST + SG * 16;          // 10 weights + 10 "before" features (f64), shared by the lanes
-  static constexpr int TOTAL = WF + 160;
-};
-
-// One decision of game g by the calling wavefront.
-template <int U>
-__device__ void decide_game(const DevBuffers& b, const int g, const int lane, int max_turns, int write_scores) {
-  typedef DecideLds<U> L;
-  typedef Engine<SharedMem<L::PAR>> ParEngine;
-  typedef Engine<LaneMem<U, L::PRIV>> CandEngine;
-  GameMeta meta = b.meta[g];
-  if (meta.result != -2) {
-    if (lane == 0) {
-      b.meta[g].last_action = 255;
-      if (b.best) b.best[g] = NAN;
-    }
-    return;
-  }
-  PROF_DECL();
-  MSB_AS_LDS u32x4* par = (MSB_AS_LDS u32x4*)(uintptr_t)L::PAR;
-  MSB_AS_LDS u32x4* priv = (MSB_AS_LDS u32x4*)(uintptr_t)L::PRIV;
-  MSB_AS_LDS u32x4* bestcol = (MSB_AS_LDS u32x4*)(uintptr_t)L::BEST;
-  u32x4* grec = (u32x4*)(b.state + (size_t)g * SW);
-  for (int c = lane; c < SG; c += 64) par[c] = grec[c];   // one coalesced 16-B-per-lane pass
-  __syncthreads();
-
-  ParEngine pe;
-  if (lane == 0) attach_rng(pe, b, g, meta.rng);
-  __syncthreads();
-
-  // rollout contract: while not have_winner() and steps < max_turns
-  if (pe.have_winner() || meta.steps >= max_turns) {
-    if (lane == 0) {
-      int b0 = pe.pl_base(0), b1 = pe.pl_base(1);
-      int res = -1;
-      if (pe.have_winner()) res = (b1 < 0 && b0 >= 0) ? 0 : (b0 < 0 && b1 >= 0) ? 1 : -1;
-      meta.result = (int8_t)res;
-      meta.last_action = 255;
-      if (pe.have_winner()) meta.flags |= 1;
-      b.meta[g] = meta;
-      if (b.best) b.best[g] = NAN;
-    }
-    return;
-  }
-
-  PROF_MARK(0);   // stage
-  const msb_u64x4 lm = pe.legal_mask_v();
-  // the legal set as wave-uniform scalars; `rem` loses the U lowest actions after every pass, so a lane finds its
-  // action among the first U set bits (at most U - 1 steps, on the scalar unit for the common part)
-  auto uni64 = [](unsigned long long v) {
-    unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v);
-    unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v >> 32));
-    return ((unsigned long long)hi << 32) | lo;
-  };
-  const uint64_t mask[3] = {uni64(lm[0]), uni64(lm[1]), uni64(lm[2])};
-  uint64_t rem[3] = {mask[0], mask[1], mask[2]};
-  const int n_legal = __popcll(mask[0]) + __popcll(mask[1]) + __popcll(mask[2]);
-  PROF_MARK(1);   // legal mask
-  const bool before_raises = pe.observation_raises();
-  // weights and "before" features are parked in LDS: 40 fewer live VGPRs across the recursive step calls
-  MSB_AS_LDS double* wf = (MSB_AS_LDS double*)(uintptr_t)L::WF;
-  {
-    const double* wt = b.weights + (size_t)(pe.local() == 0 ? meta.p1 : meta.p2) * 10;
-    if (lane < 10) wf[lane] = wt[lane];
-    // The "before" features of this decision are the "after" features the previous decision computed for the
-    // successor it committed (same state, same mover): they were kept by action id.
-    if (!before_raises) {
-      if ((meta.flags & 2) && meta.last_action < MONSOON_NUM_ACTIONS) {
-        if (lane < 10) wf[10 + lane] = b.cfeat[((size_t)g * MONSOON_NUM_ACTIONS + meta.last_action) * 10 + lane];
-      } else {
-        double fb[10];
-        pe.features(fb);
-        if (lane == 0)
-          for (int i = 0; i < 10; i++) wf[10 + i] = fb[i];
-      }
-    }
-  }
-  __syncthreads();
-  PROF_MARK(2);   // before-features
-
-  CandEngine ce;
-  // Running best over the passes (uniform across the wave).  When the legal set needs more than
-  // one pass, the best successor so far is parked in a spare LDS column so that nothing is replayed.
-  constexpr int NONE_A = 1 << 20;
-  double run_s = 0.0;
-  int run_a = NONE_A;
-  uint32_t new_pos = 0;
-  int cfault = 0;
-  int feat_ok = 0;                  // the committed successor's features are in cfeat[A]
-  int wl = 0;                       // column (lane) holding the committed successor
-  const bool multi = n_legal > U;
-  for (int base = 0; base < n_legal; base += U) {
-    int k = base + lane;
-    double s = 0.0;   // except Exception -> 0.0 (evo/heuristic_agent.py:48-51)
-    int a = NONE_A;
-    uint32_t my_pos = 0;
-    int my_fault = 0;
-    int my_feat = 0;
-    int f = 0;
-    bool raises = false;
-    // copy.deepcopy (stream window included) for the whole pass, by all 64 lanes: granule idx of the interleaved
-    // candidate image is parent granule idx / U for column idx % U
-    {
-      const int n_act = n_legal - base < U ? n_legal - base : U;
-      __syncthreads();
-      for (int idx = lane; idx < SG * U; idx += 64)
-        if ((idx & (U - 1)) < n_act) priv[idx] = par[idx / U];
-      __syncthreads();
-    }
-    if (lane < U && k < n_legal) a = nth_set_bit(rem, lane);
-    for (int i = 0; i < U; i++) {   // uniform: drop this pass's actions
-      if (rem[0]) rem[0] &= rem[0] - 1;
-      else if (rem[1]) rem[1] &= rem[1] - 1;
-      else rem[2] &= rem[2] - 1;
-    }
-    PROF_MARK(3);   // clone
-    if (lane < U && k < n_legal) {
-      ce.step(a);
-      f = ce.fault();
-      raises = f == 0 && ce.observation_raises();
-    }
-    PROF_MARK(4);   // step
-    if (lane < U && k < n_legal) {
-      if (f == 0 && !before_raises && !raises) {
-        double fa[10], wv[10], fbv[10];
-        ce.features(fa);
-        for (int i = 0; i < 10; i++) {
-          wv[i] = wf[i];
-          fbv[i] = wf[10 + i];
-        }
-        s = CandEngine::action_score(wv, fbv, fa);
-        double* slot = b.cfeat + ((size_t)g * MONSOON_NUM_ACTIONS + a) * 10;
-        for (int i = 0; i < 10; i++) slot[i] = fa[i];
-        my_feat = 1;
-      }
-      if (write_scores) b.scores[(size_t)g * MONSOON_NUM_ACTIONS + a] = s;
-      my_pos = ce.rng_pos();
-      my_fault = f ? f : (raises ? FAULT_INT_CARD : 0);
-    }
-    PROF_MARK(5);   // after-features + score
-    // first maximum over the ascending legal list == (max score, then min action id)
-    // only lanes 0..U-1 hold candidates: butterfly over those, then broadcast lane 0's result to the wave
-    double cs = s;
-    int ca = a;
-    for (int off = U / 2; off >= 1; off >>= 1) {
-      double os = __shfl_xor(cs, off);
-      int oa = __shfl_xor(ca, off);
-      bool take = (oa != NONE_A) && (ca == NONE_A || os > cs || (os == cs && oa < ca));
-      if (take) {
-        cs = os;
-        ca = oa;
-      }
-    }
-    {
-      const unsigned long long bits = (unsigned long long)__double_as_longlong(cs);
-      const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)bits);
-      const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(bits >> 32));
-      cs = __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
-      ca = __builtin_amdgcn_readfirstlane(ca);
-    }
-    if (ca != NONE_A && (run_a == NONE_A || cs > run_s)) {   // later passes hold larger action ids: strict >
-      run_s = cs;
-      run_a = ca;
-      unsigned long long bal = __ballot(a == ca);
-      wl = __ffsll((long long)bal) - 1;
-      new_pos = (uint32_t)__builtin_amdgcn_readlane((int)my_pos, wl);
-      cfault = __builtin_amdgcn_readlane(my_fault, wl);
-      feat_ok = __builtin_amdgcn_readlane(my_feat, wl);
-      if (multi) {
-        __syncthreads();
-        for (int c = lane; c < SG; c += 64) bestcol[c] = priv[c * U + wl];
-        __syncthreads();
-      }
-    }
-    PROF_MARK(6);   // argmax + park
-  }
-  const int A = run_a;
-  const double rs = run_s;
-  __syncthreads();
-  // commit: adapter = adapter.apply_action(best)
-  if (multi) {
-    for (int c = lane; c < SG; c += 64) grec[c] = bestcol[c];
-  } else {
-    for (int c = lane; c < SG; c += 64) grec[c] = priv[c * U + wl];
-  }
-  __syncthreads();
-  int cur = (meta.rng >> 16) & 1;
-  if (new_pos >= (uint32_t)MT_N) {
-    new_pos -= MT_N;
-    wave_refill(b, g, cur, (MSB_AS_LDS uint32_t*)priv, lane);   // the used-up block becomes the new "next" block
-    cur ^= 1;
-  }
-  if (lane == 0) {
-    meta.rng = new_pos | ((uint32_t)cur << 16);
-    meta.steps++;
-    meta.last_action = (uint8_t)A;
-    int executed = n_legal;   // every legal action is stepped exactly once; the commit re-executes nothing
-    meta.lookahead += (uint32_t)executed;
-    meta.flags = (uint8_t)((meta.flags & ~2) | (feat_ok ? 2 : 0));
-    meta.decided++;   // statistics are per-game fields reduced on demand (k_stats): no same-address atomics here
-    if (cfault) {
-      // evo/fitness.py:208-210: an exception while applying the action ends the game as a draw
-      meta.fault = (uint8_t)cfault;
-      meta.result = -1;
-    }
-    b.meta[g] = meta;
-    if (b.best) b.best[g] = rs;
-  }
-  PROF_MARK(7);   // commit + refill
-  PROF_FLUSH();
-}
-
-// Hot kernel.  Persistent wavefronts: the grid is what the GPU holds at once.  The games are split into
-// POP_PARTS contiguous ranges; wavefront w works on range w % POP_PARTS (workgroups are dealt to the 8 XCDs round-
-// robin, so a range stays on one XCD and its L2): it starts with the game given by its index and then pops further
-// ones from the range's counter, the pop being issued before the current game is played so that its latency is
-// hidden.  Games stay in index order -- neighbouring records, stream blocks and meta rows are touched together;
-// sorting the games by expected cost was measured 5-8 % slower.  One counter per range, 128 bytes apart: atomics
-// on ONE address serialise at ~25 ns each, which capped the whole launch at 65 536 x 25 ns (the same trap as
-// per-game statistics counters; see k_stats).  Every wave reaches its exit (t >= hi): counters only grow.
-// b.pop[parity] is this launch's set; the other one is cleared for the next launch.  persistent = 0: one workgroup
-// per game.
-constexpr int POP_PARTS = 8, POP_STRIDE = 32;
-template <int U, int WPE>
-__global__ void __launch_bounds__(64, WPE) k_decide(DevBuffers b, int n, int max_turns, int write_scores, int persistent, int parity) {
-  const int lane = threadIdx.x;
-  if (!persistent) {
-    if ((int)blockIdx.x < n) decide_game<U>(b, blockIdx.x, lane, max_turns, write_scores);
-    return;
-  }
-  int* mine = b.pop + parity * POP_PARTS * POP_STRIDE;
-  int* other = b.pop + (parity ^ 1) * POP_PARTS * POP_STRIDE;
-  if (blockIdx.x == 0 && lane < POP_PARTS) other[lane * POP_STRIDE] = 0;
-  const int part = blockIdx.x % POP_PARTS, rank = blockIdx.x / POP_PARTS;
-  const int waves = ((int)gridDim.x - part + POP_PARTS - 1) / POP_PARTS;   // wavefronts working on this range
-  const int lo = (int)((long long)n * part / POP_PARTS), hi = (int)((long long)n * (part + 1) / POP_PARTS);
-  int t = lo + rank;
-  while (t < hi) {
-    int nxt = 0x7fffffff;
-    if (lane == 0) nxt = lo + waves + atomicAdd(&mine[part * POP_STRIDE], 1);
-    decide_game<U>(b, t, lane, max_turns, write_scores);
-    __syncthreads();   // the LDS image is reused by the next game
-    t = __builtin_amdgcn_readfirstlane(nxt);
-  }
-}
-
 // Statistics of the loaded games, reduced from the per-game fields: {look-ahead steps, decisions, games ended by a
-// winner, games stopped by a fault, of those build-limit faults}.  One atomic per wavefront into a zeroed buffer.
+// winner, games stopped by a fault, of those build-limit faults, games with a build-limit fault inside a look-ahead}.
+// One atomic per wavefront into a zeroed buffer.
 __global__ void __launch_bounds__(256) k_stats(DevBuffers b, int n, unsigned long long* out) {
-  unsigned long long v[5] = {0, 0, 0, 0, 0};
+  unsigned long long v[ST_N] = {0, 0, 0, 0, 0, 0};
   for (int g = blockIdx.x * blockDim.x + threadIdx.x; g < n; g += gridDim.x * blockDim.x) {
     GameMeta m = b.meta[g];
     v[0] += m.lookahead;
@@ -648,17 +218,19 @@ __global__ void __launch_bounds__(256) k_stats(DevBuffers b, int n, unsigned lon
     v[2] += (m.flags & 1) ? 1 : 0;
     v[3] += (m.result == -1 && m.fault) ? 1 : 0;
     v[4] += (m.result == -1 && m.fault >= FAULT_CAPACITY) ? 1 : 0;
+    v[5] += m.la_fault ? 1 : 0;
   }
-  for (int i = 0; i < 5; i++) {
+  for (int i = 0; i < ST_N; i++) {
     unsigned long long x = v[i];
     for (int off = 32; off >= 1; off >>= 1) x += __shfl_xor(x, off);
     if ((threadIdx.x & 63) == 0 && x) atomicAdd(&out[i], x);
   }
 }
 
+// per game: the fault that stopped it, else the first build-limit fault one of its look-aheads hit (0 = none)
 __global__ void k_faults(DevBuffers b, int n, uint8_t* out) {
   int g = blockIdx.x * blockDim.x + threadIdx.x;
-  if (g < n) out[g] = b.meta[g].fault;
+  if (g < n) out[g] = b.meta[g].fault ? b.meta[g].fault : b.meta[g].la_fault;
 }
 
 __global__ void k_clear_scores(double* scores, size_t n) {
@@ -666,18 +238,12 @@ __global__ void k_clear_scores(double* scores, size_t n) {
   if (i < n) scores[i] = NAN;
 }
 
-__global__ void k_assign(DevBuffers b, int n, const int32_t* p1, const int32_t* p2) {
+__global__ void k_assign(DevBuffers b, int n, const int32_t* p1, const int32_t* p2, int match_base) {
   int g = blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= n) return;
   b.meta[g].p1 = p1[g];
   b.meta[g].p2 = p2[g];
-}
-
-// Count live games (rollout loop exit test) and collect per-individual tallies.
-__global__ void k_count_live(DevBuffers b, int n, int* live) {
-  int g = blockIdx.x * blockDim.x + threadIdx.x;
-  if (g >= n) return;
-  if (b.meta[g].result == -2) atomicAdd(live, 1);
+  b.meta[g].match = (uint32_t)(match_base + g);
 }
 
 __global__ void k_collect(DevBuffers b, int n, int32_t* counts, int8_t* results, int32_t* steps) {
@@ -707,10 +273,27 @@ __global__ void k_collect(DevBuffers b, int n, int32_t* counts, int8_t* results,
   if (steps) steps[m.match] = m.steps;
 }
 
-__global__ void k_set_match(DevBuffers b, int n, int base) {
-  int g = blockIdx.x * blockDim.x + threadIdx.x;
-  if (g >= n) return;
-  b.meta[g].match = base + g;
+// monsoon_state_save / monsoon_state_load: one game's complete device state as a flat blob
+// {u32 magic, u32 record bytes, GameMeta, record, raw MT state, two tempered blocks}
+constexpr uint32_t BLOB_MAGIC = 0x4d53424cu ^ (uint32_t)STATE_BYTES;
+constexpr int BLOB_BYTES = 8 + (int)sizeof(GameMeta) + STATE_BYTES + MT_N * 4 + RNG_WORDS * 4;
+__global__ void k_blob(DevBuffers b, int g, uint32_t* blob, int load) {
+  const int t = threadIdx.x;
+  uint32_t* meta = (uint32_t*)(b.meta + g);
+  uint32_t* parts[4] = {meta, b.state + (size_t)g * SW, b.rng_mt + (size_t)g * MT_N, b.rng_out + (size_t)g * RNG_WORDS};
+  const int words[4] = {(int)sizeof(GameMeta) / 4, SW, MT_N, RNG_WORDS};
+  int off = 2;
+  if (!load && t == 0) {
+    blob[0] = BLOB_MAGIC;
+    blob[1] = (uint32_t)STATE_BYTES;
+  }
+  for (int p = 0; p < 4; p++) {
+    for (int i = t; i < words[p]; i += blockDim.x) {
+      if (load) parts[p][i] = blob[off + i];
+      else blob[off + i] = parts[p][i];
+    }
+    off += words[p];
+  }
 }
 
 }  // namespace
@@ -720,31 +303,39 @@ __global__ void k_set_match(DevBuffers b, int n, int base) {
 // ================================================================================================
 struct monsoon {
   monsoon_config cfg;
-  int device;
-  hipStream_t stream;
+  int device = 0;
+  hipStream_t stream = nullptr;
   DevBuffers b;
-  int wpe;            // k_decide variant: __launch_bounds__ waves per SIMD
-  int parity;         // which of b.pop the next k_decide launch uses
-  unsigned long long st_acc[5], st_base[5];   // statistics: totals of earlier batches, baseline of the loaded one
-  int grid_waves;     // persistent grid size of k_decide (resident wavefronts), 0 = not yet queried
-  int n;              // games loaded by the last reset
-  int n_individuals;
+  const VariantOps* var = nullptr;   // hot-kernel variant: candidate lanes per game, waves per SIMD
+  int parity = 0;     // which of b.pop the next k_decide launch uses
+  unsigned long long st_acc[ST_N], st_base[ST_N];   // statistics: totals of earlier batches, baseline of the loaded one
+  int grid_waves = 0; // persistent grid size of k_decide (resident wavefronts), 0 = not yet queried
+  int n = 0;          // games loaded by the last reset
+  int n_individuals = 0;   // rows of the uploaded weight table
+  int weights_cap = 0;     // rows allocated
   std::string err;
   // scratch device buffers for API calls
-  uint8_t* d_bytes;   // cap * max(24, 1024/…)
-  uint8_t* d_decks;   // [cap][24]
-  uint8_t* d_factions;
-  uint32_t* d_seeds;
-  uint64_t* d_masks;
-  int32_t* d_i32;     // cap * 540
-  double* d_f64;      // cap * 10
-  int32_t* d_p1;
-  int32_t* d_p2;
-  int* d_int;
-  hipEvent_t ev0, ev1;
-  std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;   // decide-kernel timing pairs
-  double kernel_ms;
-  long long kernel_launches;
+  uint8_t* d_bytes = nullptr;   // max(cap * 8, 16 KiB)
+  uint8_t* d_decks = nullptr;   // [cap][24]
+  uint8_t* d_factions = nullptr;
+  uint32_t* d_seeds = nullptr;
+  uint64_t* d_masks = nullptr;
+  int32_t* d_i32 = nullptr;     // cap * 540
+  double* d_f64 = nullptr;      // cap * 10
+  int32_t* d_p1 = nullptr;
+  int32_t* d_p2 = nullptr;
+  int* d_int = nullptr;
+  // rollout result buffers, grown on demand and kept for the life of the handle
+  int32_t* d_counts = nullptr;
+  size_t counts_cap = 0;
+  int8_t* d_results = nullptr;
+  int32_t* d_steps = nullptr;
+  size_t matches_cap = 0;
+  // kernel timing: event pairs are created once and reused
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
+  size_t ev_used = 0;
+  double kernel_ms = 0;
+  long long kernel_launches = 0;
 };
 
 static std::string g_create_error;
@@ -774,13 +365,34 @@ static bool card_unsupported(int c) {
 #endif
 }
 
+// k_play instantiations of this build (variants.def): each one is a full compilation of the rules core
+// in a translation unit of its own; anything else is refused by monsoon_create.
+#include "variants.def"
+#define X(U, W) const VariantOps* monsoon_variant_##U##_##W();
+MSB_VARIANTS(X)
+#undef X
+static const VariantOps* find_variant(int u, int w) {   // w = 0: the build of u lanes with the most waves per SIMD
+  const VariantOps* best = nullptr;
+#define X(U, W) if (u == U && (w == W || (w == 0 && (!best || W > best->wpe)))) best = monsoon_variant_##U##_##W();
+  MSB_VARIANTS(X)
+#undef X
+  return best;
+}
+static const VariantOps* default_variant() {
+  const VariantOps* first = nullptr;
+#define X(U, W) if (!first) first = monsoon_variant_##U##_##W();
+  MSB_VARIANTS(X)
+#undef X
+  return first;
+}
+
 extern "C" {
 
 int monsoon_version(void) {
 #if defined(MSB_EXT) && MSB_EXT
-  return 0x10001;   // bit 16: extended record
+  return 0x10002;   // bit 16: extended record
 #else
-  return 1;
+  return 2;
 #endif
 }
 
@@ -797,11 +409,13 @@ const char* monsoon_last_error(monsoon_t* h) { return h ? h->err.c_str() : g_cre
 void monsoon_destroy(monsoon_t* h) {
   if (!h) return;
   hipSetDevice(h->device);
-  void* ptrs[] = {h->b.state, h->b.rng_out, h->b.rng_mt, h->b.meta, h->b.weights, h->b.stats, h->b.scores, h->b.best, h->b.prof, h->b.pop, h->b.cfeat,
-                  h->d_bytes, h->d_decks, h->d_factions, h->d_seeds, h->d_masks, h->d_i32, h->d_f64, h->d_p1, h->d_p2, h->d_int};
+  if (h->stream) hipStreamSynchronize(h->stream);
+  void* ptrs[] = {h->b.state, h->b.rng_out, h->b.rng_mt, h->b.meta, h->b.weights, h->b.stats, h->b.scores, h->b.best, h->b.prof, h->b.pop,
+                  h->d_bytes, h->d_decks, h->d_factions, h->d_seeds, h->d_masks, h->d_i32, h->d_f64, h->d_p1, h->d_p2, h->d_int,
+                  h->d_counts, h->d_results, h->d_steps};
   for (void* p : ptrs)
     if (p) hipFree(p);
-  for (auto& pr : h->pending) {
+  for (auto& pr : h->ev_pool) {
     hipEventDestroy(pr.first);
     hipEventDestroy(pr.second);
   }
@@ -809,47 +423,9 @@ void monsoon_destroy(monsoon_t* h) {
   delete h;
 }
 
-int monsoon_create(const monsoon_config* cfg, monsoon_t** out) {
-  if (!cfg || !out || cfg->max_games <= 0) {
-    g_create_error = "monsoon_create: bad config";
-    return MONSOON_ERR_ARG;
-  }
-  int ndev = 0;
-  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0 || cfg->device >= ndev) {
-    g_create_error = "monsoon_create: no usable HIP device (this library has no CPU path)";
-    return MONSOON_ERR_DEVICE;
-  }
-  hipDeviceProp_t prop;
-  if (hipGetDeviceProperties(&prop, cfg->device) != hipSuccess) {
-    g_create_error = "monsoon_create: hipGetDeviceProperties failed";
-    return MONSOON_ERR_DEVICE;
-  }
-  if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
-    g_create_error = std::string("monsoon_create: built for gfx950, device is ") + prop.gcnArchName;
-    return MONSOON_ERR_DEVICE;
-  }
-  monsoon* h = new monsoon();
-  memset(&h->b, 0, sizeof(h->b));
-  h->cfg = *cfg;
-  if (h->cfg.lanes_per_game != 8 && h->cfg.lanes_per_game != 16 && h->cfg.lanes_per_game != 32 && h->cfg.lanes_per_game != 64)
-    h->cfg.lanes_per_game = 8;
-  h->wpe = h->cfg.lanes_per_game == 8 ? 4 : 2;
-  if (const char* e = getenv("MONSOON_WPE")) h->wpe = atoi(e);   // tuning knob: min waves per SIMD the kernel is built for
-  if (h->cfg.stack_bytes <= 0) h->cfg.stack_bytes = 16384;
-  h->device = cfg->device;
-  h->n = 0;
-  h->n_individuals = 0;
-  h->stream = nullptr;
-  h->d_bytes = nullptr; h->d_decks = nullptr; h->d_factions = nullptr; h->d_seeds = nullptr; h->d_masks = nullptr;
-  h->d_i32 = nullptr; h->d_f64 = nullptr; h->d_p1 = nullptr; h->d_p2 = nullptr; h->d_int = nullptr;
-  h->kernel_ms = 0;
-  h->kernel_launches = 0;
-  h->parity = 0;
-  h->grid_waves = 0;
-  memset(h->st_acc, 0, sizeof(h->st_acc));
-  memset(h->st_base, 0, sizeof(h->st_base));
-  *out = h;
-  size_t cap = (size_t)cfg->max_games;
+static int create_impl(monsoon* h) {
+  const monsoon_config& cfg = h->cfg;
+  size_t cap = (size_t)cfg.max_games;
   HIP_TRY(h, hipSetDevice(h->device));
   // the rules core recurses (move -> ability -> ...): give every lane a scratch stack
   HIP_TRY(h, hipDeviceSetLimit(hipLimitStackSize, (size_t)h->cfg.stack_bytes));
@@ -862,7 +438,6 @@ int monsoon_create(const monsoon_config* cfg, monsoon_t** out) {
   HIP_TRY(h, hipMalloc(&h->b.stats, ST_WORDS * sizeof(unsigned long long)));
   HIP_TRY(h, hipMemset(h->b.stats, 0, ST_WORDS * sizeof(unsigned long long)));
   HIP_TRY(h, hipMalloc(&h->b.best, cap * sizeof(double)));
-  HIP_TRY(h, hipMalloc(&h->b.cfeat, cap * MONSOON_NUM_ACTIONS * 10 * sizeof(double)));
   HIP_TRY(h, hipMalloc(&h->b.pop, 2 * 8 * 32 * sizeof(int)));
   HIP_TRY(h, hipMemset(h->b.pop, 0, 2 * 8 * 32 * sizeof(int)));
 #if defined(MSB_PROF) && MSB_PROF
@@ -873,10 +448,71 @@ int monsoon_create(const monsoon_config* cfg, monsoon_t** out) {
   HIP_TRY(h, hipMalloc(&h->d_factions, cap * 2));
   HIP_TRY(h, hipMalloc(&h->d_seeds, cap * 4));
   HIP_TRY(h, hipMalloc(&h->d_masks, cap * 24));
-  HIP_TRY(h, hipMalloc(&h->d_bytes, cap * 8 > 4096 ? cap * 8 : 4096));
+  HIP_TRY(h, hipMalloc(&h->d_bytes, cap * 8 > 16384 ? cap * 8 : 16384));
   HIP_TRY(h, hipMalloc(&h->d_p1, cap * 4));
   HIP_TRY(h, hipMalloc(&h->d_p2, cap * 4));
   HIP_TRY(h, hipMalloc(&h->d_int, 64));
+  return MONSOON_OK;
+}
+
+int monsoon_create(const monsoon_config* cfg, monsoon_t** out) {
+  if (out) *out = nullptr;
+  if (!cfg || !out || cfg->max_games <= 0) {
+    g_create_error = "monsoon_create: bad config";
+    return MONSOON_ERR_ARG;
+  }
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0 || cfg->device < 0 || cfg->device >= ndev) {
+    g_create_error = "monsoon_create: no usable HIP device (this library has no CPU path)";
+    return MONSOON_ERR_DEVICE;
+  }
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, cfg->device) != hipSuccess) {
+    g_create_error = "monsoon_create: hipGetDeviceProperties failed";
+    return MONSOON_ERR_DEVICE;
+  }
+  if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+    g_create_error = std::string("monsoon_create: built for gfx950, device is ") + prop.gcnArchName;
+    return MONSOON_ERR_DEVICE;
+  }
+  // kernel variant: 0 = this build's default; an explicit value without an instantiation is an error, never a
+  // silent substitute (tuning knobs for experiments: MONSOON_LANES / MONSOON_WPE)
+  int u = cfg->lanes_per_game, w = 0;
+  if (const char* e = getenv("MONSOON_LANES")) u = atoi(e);
+  if (const char* e = getenv("MONSOON_WPE")) w = atoi(e);
+  const VariantOps* var = default_variant();
+  if (u != 0 || w != 0) {
+    if (u == 0) u = var->lanes;
+    if (w == 0 && u == var->lanes) w = var->wpe;
+    var = find_variant(u, w);
+  }
+  if (!var) {
+    g_create_error = "monsoon_create: no kernel variant for lanes_per_game=" + std::to_string(u) + " waves_per_simd=" + std::to_string(w) +
+                     " in this build (monsoon_amd/csrc/variants.def)";
+    return MONSOON_ERR_ARG;
+  }
+  monsoon* h = new monsoon();
+  memset(&h->b, 0, sizeof(h->b));
+  h->cfg = *cfg;
+  h->var = var;
+  if (h->cfg.stack_bytes <= 0) h->cfg.stack_bytes = 16384;
+  h->device = cfg->device;
+  memset(h->st_acc, 0, sizeof(h->st_acc));
+  memset(h->st_base, 0, sizeof(h->st_base));
+  int rc = create_impl(h);
+  if (rc != MONSOON_OK) {
+    g_create_error = "monsoon_create: " + h->err;
+    monsoon_destroy(h);
+    return rc;
+  }
+  *out = h;
+  return MONSOON_OK;
+}
+
+int monsoon_variant(monsoon_t* h, int32_t* lanes_per_game, int32_t* waves_per_simd) {
+  if (!h) return MONSOON_ERR_ARG;
+  if (lanes_per_game) *lanes_per_game = h->var->lanes;
+  if (waves_per_simd) *waves_per_simd = h->var->wpe;
   return MONSOON_OK;
 }
 
@@ -903,23 +539,26 @@ static int launch_reset(monsoon_t* h, int n) {
 
 static int fold_stats(monsoon_t* h);
 
+static int check_decks(monsoon_t* h, const uint8_t* decks, size_t n_cards, const char* who) {
+  for (size_t i = 0; i < n_cards; i++) {
+    if (decks[i] >= NUM_CARDS || card_unsupported(decks[i])) {
+      h->err = std::string(who) + ": card not supported by this build: " + (decks[i] < NUM_CARDS ? kCardIds[decks[i]] : "index out of range");
+      return MONSOON_ERR_ARG;
+    }
+  }
+  return MONSOON_OK;
+}
+
 int monsoon_reset(monsoon_t* h, int32_t n, const uint32_t* seeds, const uint8_t* decks, const uint8_t* factions) {
   if (!h || !seeds || !decks || n <= 0 || n > h->cfg.max_games) {
     if (h) h->err = "monsoon_reset: bad argument";
     return MONSOON_ERR_ARG;
   }
-  for (size_t i = 0; i < (size_t)n * 24; i++) {
-    if (decks[i] >= NUM_CARDS || card_unsupported(decks[i])) {
-      h->err = std::string("monsoon_reset: card not supported by this build: ") +
-               (decks[i] < NUM_CARDS ? kCardIds[decks[i]] : "index out of range");
-      return MONSOON_ERR_ARG;
-    }
-  }
+  int rc = check_decks(h, decks, (size_t)n * 24, "monsoon_reset");
+  if (rc) return rc;
   HIP_TRY(h, hipSetDevice(h->device));
-  {
-    int rc = fold_stats(h);   // statistics live in the per-game rows that are about to be cleared
-    if (rc) return rc;
-  }
+  rc = fold_stats(h);   // statistics live in the per-game rows that are about to be cleared
+  if (rc) return rc;
   HIP_TRY(h, hipMemcpyAsync(h->d_seeds, seeds, (size_t)n * 4, hipMemcpyHostToDevice, h->stream));
   HIP_TRY(h, hipMemcpyAsync(h->d_decks, decks, (size_t)n * 24, hipMemcpyHostToDevice, h->stream));
   if (factions)
@@ -927,7 +566,7 @@ int monsoon_reset(monsoon_t* h, int32_t n, const uint32_t* seeds, const uint8_t*
   else
     HIP_TRY(h, hipMemsetAsync(h->d_factions, 0, (size_t)n * 2, h->stream));
   HIP_TRY(h, hipMemsetAsync(h->b.meta, 0, (size_t)n * sizeof(GameMeta), h->stream));
-  int rc = launch_reset(h, n);
+  rc = launch_reset(h, n);
   if (rc) return rc;
   HIP_TRY(h, hipStreamSynchronize(h->stream));
   h->n = n;
@@ -951,6 +590,21 @@ int monsoon_step(monsoon_t* h, const uint8_t* actions, int8_t* reward, uint8_t* 
   if (rc) return rc;
   if (!actions) return MONSOON_ERR_ARG;
   int n = h->n;
+  // Every action is checked against its game's legal set BEFORE any game is stepped: an illegal entry refuses the
+  // whole call and leaves every game untouched.
+  {
+    std::vector<uint64_t> masks((size_t)n * 3);
+    rc = monsoon_legal_mask(h, masks.data());
+    if (rc) return rc;
+    for (int i = 0; i < n; i++) {
+      int a = actions[i];
+      if (a == 255 || a == 155) continue;   // skip / PASS (always accepted, see k_step)
+      if (a >= MONSOON_NUM_ACTIONS || !((masks[(size_t)i * 3 + (a >> 6)] >> (a & 63)) & 1)) {
+        h->err = "monsoon_step: illegal action " + std::to_string(a) + " for game " + std::to_string(i);
+        return MONSOON_ERR_ARG;
+      }
+    }
+  }
   uint8_t* d = h->d_bytes;   // [actions | reward | done | fault | illegal] x n
   HIP_TRY(h, hipMemcpyAsync(d, actions, n, hipMemcpyHostToDevice, h->stream));
   hipLaunchKernelGGL(k_step, dim3((n + API_LANES - 1) / API_LANES), dim3(64), API_LDS_BYTES, h->stream, h->b, n, d, (int8_t*)(d + n), d + 2 * (size_t)n,
@@ -959,12 +613,6 @@ int monsoon_step(monsoon_t* h, const uint8_t* actions, int8_t* reward, uint8_t* 
   std::vector<uint8_t> host(4 * (size_t)n);
   HIP_TRY(h, hipMemcpyAsync(host.data(), d + n, 4 * (size_t)n, hipMemcpyDeviceToHost, h->stream));
   HIP_TRY(h, hipStreamSynchronize(h->stream));
-  for (int i = 0; i < n; i++) {
-    if (host[3 * (size_t)n + i]) {
-      h->err = "monsoon_step: illegal action " + std::to_string(actions[i]) + " for game " + std::to_string(i);
-      return MONSOON_ERR_ARG;
-    }
-  }
   if (reward) memcpy(reward, host.data(), n);
   if (done) memcpy(done, host.data() + n, n);
   if (fault) memcpy(fault, host.data() + 2 * (size_t)n, n);
@@ -1036,7 +684,7 @@ int monsoon_status(monsoon_t* h, int32_t* out) {
   if (!out) return MONSOON_ERR_ARG;
   int n = h->n;
   if (!h->d_i32) HIP_TRY(h, hipMalloc(&h->d_i32, (size_t)h->cfg.max_games * MONSOON_OBS_INTS * 4));
-  hipLaunchKernelGGL(k_status, dim3((n + API_LANES - 1) / API_LANES), dim3(64), 0, h->stream, h->b, n, h->d_i32);
+  hipLaunchKernelGGL(k_status, dim3((n + 63) / 64), dim3(64), 0, h->stream, h->b, n, h->d_i32);
   HIP_TRY(h, hipGetLastError());
   HIP_TRY(h, hipMemcpyAsync(out, h->d_i32, (size_t)n * 16, hipMemcpyDeviceToHost, h->stream));
   HIP_TRY(h, hipStreamSynchronize(h->stream));
@@ -1070,6 +718,43 @@ int monsoon_debug_raw(monsoon_t* h, int32_t idx, uint8_t* buf, int32_t* len) {
   return MONSOON_OK;
 }
 
+// copy.deepcopy(game) across the boundary: the complete device state of one game (record, meta row, stream) as an
+// opaque blob that monsoon_state_load puts back into any slot of any handle of the same build.
+int32_t monsoon_state_blob_bytes(void) { return BLOB_BYTES; }
+
+int monsoon_state_save(monsoon_t* h, int32_t idx, uint8_t* buf, int32_t buf_bytes) {
+  int rc = check_ready(h);
+  if (rc) return rc;
+  if (!buf || buf_bytes < BLOB_BYTES || idx < 0 || idx >= h->n) {
+    h->err = "monsoon_state_save: bad argument (buffer must hold monsoon_state_blob_bytes())";
+    return MONSOON_ERR_ARG;
+  }
+  static_assert(BLOB_BYTES <= 16384, "blob staging buffer");
+  hipLaunchKernelGGL(k_blob, dim3(1), dim3(256), 0, h->stream, h->b, idx, (uint32_t*)h->d_bytes, 0);
+  HIP_TRY(h, hipGetLastError());
+  HIP_TRY(h, hipMemcpyAsync(buf, h->d_bytes, BLOB_BYTES, hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  return MONSOON_OK;
+}
+
+// idx may be any slot below max_games; loading into slot h->n appends a game to the loaded batch.
+int monsoon_state_load(monsoon_t* h, int32_t idx, const uint8_t* buf, int32_t buf_bytes) {
+  if (!h || !buf) return MONSOON_ERR_ARG;
+  uint32_t head[2];
+  if (buf_bytes >= 8) memcpy(head, buf, 8);
+  if (buf_bytes < BLOB_BYTES || head[0] != BLOB_MAGIC || head[1] != (uint32_t)STATE_BYTES || idx < 0 || idx > h->n || idx >= h->cfg.max_games) {
+    h->err = "monsoon_state_load: not a state blob of this build, or slot out of range";
+    return MONSOON_ERR_ARG;
+  }
+  HIP_TRY(h, hipSetDevice(h->device));
+  HIP_TRY(h, hipMemcpyAsync(h->d_bytes, buf, BLOB_BYTES, hipMemcpyHostToDevice, h->stream));
+  hipLaunchKernelGGL(k_blob, dim3(1), dim3(256), 0, h->stream, h->b, idx, (uint32_t*)h->d_bytes, 1);
+  HIP_TRY(h, hipGetLastError());
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  if (idx == h->n) h->n = idx + 1;
+  return MONSOON_OK;
+}
+
 int monsoon_game_faults(monsoon_t* h, uint8_t* out) {
   int rc = check_ready(h);
   if (rc) return rc;
@@ -1097,21 +782,22 @@ int monsoon_state_hash(monsoon_t* h, uint64_t* out) {
 int monsoon_upload_weights(monsoon_t* h, const double* weights, int32_t n_individuals) {
   if (!h || !weights || n_individuals <= 0) return MONSOON_ERR_ARG;
   HIP_TRY(h, hipSetDevice(h->device));
-  if (n_individuals > h->n_individuals) {
+  if (n_individuals > h->weights_cap) {
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
     if (h->b.weights) HIP_TRY(h, hipFree(h->b.weights));
     h->b.weights = nullptr;
+    h->weights_cap = 0;
+    h->n_individuals = 0;
     HIP_TRY(h, hipMalloc(&h->b.weights, (size_t)n_individuals * 80));
-    h->n_individuals = n_individuals;
+    h->weights_cap = n_individuals;
   }
   HIP_TRY(h, hipMemcpyAsync(h->b.weights, weights, (size_t)n_individuals * 80, hipMemcpyHostToDevice, h->stream));
   HIP_TRY(h, hipStreamSynchronize(h->stream));
+  h->n_individuals = n_individuals;   // rows beyond the uploaded count are stale: assign_players refuses them
   return MONSOON_OK;
 }
 
-int monsoon_assign_players(monsoon_t* h, const int32_t* p1, const int32_t* p2) {
-  int rc = check_ready(h);
-  if (rc) return rc;
-  if (!p1 || !p2) return MONSOON_ERR_ARG;
+static int assign_players(monsoon_t* h, const int32_t* p1, const int32_t* p2, int match_base) {
   int n = h->n;
   for (int i = 0; i < n; i++)
     if (p1[i] < 0 || p2[i] < 0 || p1[i] >= h->n_individuals || p2[i] >= h->n_individuals) {
@@ -1120,71 +806,80 @@ int monsoon_assign_players(monsoon_t* h, const int32_t* p1, const int32_t* p2) {
     }
   HIP_TRY(h, hipMemcpyAsync(h->d_p1, p1, (size_t)n * 4, hipMemcpyHostToDevice, h->stream));
   HIP_TRY(h, hipMemcpyAsync(h->d_p2, p2, (size_t)n * 4, hipMemcpyHostToDevice, h->stream));
-  hipLaunchKernelGGL(k_assign, dim3((n + 255) / 256), dim3(256), 0, h->stream, h->b, n, h->d_p1, h->d_p2);
+  hipLaunchKernelGGL(k_assign, dim3((n + 255) / 256), dim3(256), 0, h->stream, h->b, n, h->d_p1, h->d_p2, match_base);
   HIP_TRY(h, hipGetLastError());
   HIP_TRY(h, hipStreamSynchronize(h->stream));
   return MONSOON_OK;
 }
 
-static int launch_decide(monsoon_t* h, int n, int max_turns, int write_scores, bool timed) {
-  hipEvent_t e0 = nullptr, e1 = nullptr;
-  if (timed) {
+int monsoon_assign_players(monsoon_t* h, const int32_t* p1, const int32_t* p2) {
+  int rc = check_ready(h);
+  if (rc) return rc;
+  if (!p1 || !p2) return MONSOON_ERR_ARG;
+  return assign_players(h, p1, p2, 0);
+}
+
+// a reusable pair of timing events (created once per handle, recycled by drain_timing)
+static int timing_begin(monsoon_t* h, size_t* slot) {
+  if (h->ev_used == h->ev_pool.size()) {
+    hipEvent_t e0 = nullptr, e1 = nullptr;
     HIP_TRY(h, hipEventCreate(&e0));
-    HIP_TRY(h, hipEventCreate(&e1));
+    hipError_t e = hipEventCreate(&e1);
+    if (e != hipSuccess) {
+      hipEventDestroy(e0);
+      h->err = std::string("hipEventCreate: ") + hipGetErrorString(e);
+      return MONSOON_ERR_DEVICE;
+    }
+    h->ev_pool.emplace_back(e0, e1);
   }
-  static const int persistent = getenv("MONSOON_PERSIST") ? atoi(getenv("MONSOON_PERSIST")) : 1;
-  static const int lds_pad = getenv("MONSOON_LDS_PAD") ? atoi(getenv("MONSOON_LDS_PAD")) : 0;   // occupancy experiments only
-  if (timed) HIP_TRY(h, hipEventRecord(e0, h->stream));
-#define MSB_LAUNCH(U, W)                                                                                                \
-  do {                                                                                                                  \
-    if (!h->grid_waves) {                                                                                               \
-      int per_cu = 0;                                                                                                   \
-      hipDeviceProp_t prop;                                                                                             \
-      HIP_TRY(h, hipGetDeviceProperties(&prop, h->device));                                                             \
-      HIP_TRY(h, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_decide<U, W>, 64, DecideLds<U>::TOTAL + lds_pad)); \
-      h->grid_waves = 2 * (per_cu > 0 ? per_cu * prop.multiProcessorCount : 4096);   /* two waves per slot: measured best */                                            \
-      if (const char* e = getenv("MONSOON_GRID")) h->grid_waves = atoi(e);                                              \
-    }                                                                                                                   \
-    int grid = (persistent && h->grid_waves < n) ? h->grid_waves : n;                                                   \
-    hipLaunchKernelGGL((k_decide<U, W>), dim3(grid), dim3(64), DecideLds<U>::TOTAL + lds_pad, h->stream, h->b, n, max_turns, write_scores, persistent, h->parity); \
-    h->parity ^= 1; \
-  } while (0)
-  int variant = h->cfg.lanes_per_game * 10 + h->wpe;
-  switch (variant) {
-    case 81: MSB_LAUNCH(8, 1); break;
-    case 82: MSB_LAUNCH(8, 2); break;
-    case 83: MSB_LAUNCH(8, 3); break;
-    case 161: MSB_LAUNCH(16, 1); break;
-    case 163: MSB_LAUNCH(16, 3); break;
-    case 164: MSB_LAUNCH(16, 4); break;
-#if !(defined(MSB_EXT) && MSB_EXT)
-    case 321: MSB_LAUNCH(32, 1); break;
-    case 322: MSB_LAUNCH(32, 2); break;
-    case 641: MSB_LAUNCH(64, 1); break;
-#endif
-    case 162: MSB_LAUNCH(16, 2); break;
-    default: MSB_LAUNCH(8, 4); break;
-  }
-#undef MSB_LAUNCH
-  HIP_TRY(h, hipGetLastError());
-  if (timed) {
-    HIP_TRY(h, hipEventRecord(e1, h->stream));
-    h->pending.emplace_back(e0, e1);
-  }
+  *slot = h->ev_used++;
+  HIP_TRY(h, hipEventRecord(h->ev_pool[*slot].first, h->stream));
   return MONSOON_OK;
 }
 
 static int drain_timing(monsoon_t* h) {
-  for (auto& pr : h->pending) {
+  for (size_t i = 0; i < h->ev_used; i++) {
+    auto& pr = h->ev_pool[i];
     HIP_TRY(h, hipEventSynchronize(pr.second));
     float ms = 0;
     HIP_TRY(h, hipEventElapsedTime(&ms, pr.first, pr.second));
     h->kernel_ms += ms;
     h->kernel_launches++;
-    hipEventDestroy(pr.first);
-    hipEventDestroy(pr.second);
   }
-  h->pending.clear();
+  h->ev_used = 0;
+  return MONSOON_OK;
+}
+
+static const int g_persistent = getenv("MONSOON_PERSIST") ? atoi(getenv("MONSOON_PERSIST")) : 1;
+static const int g_lds_pad = getenv("MONSOON_LDS_PAD") ? atoi(getenv("MONSOON_LDS_PAD")) : 0;   // occupancy experiments only
+
+// `rounds` decisions of every loaded game in ONE launch (1 = a decision round; max_turns + 1 = whole games: the extra
+// round turns "still running at the cap" into a result).
+static int launch_play(monsoon_t* h, int n, int max_turns, int rounds, int write_scores, bool timed) {
+  size_t slot = 0;
+  if (timed) {
+    int rc = timing_begin(h, &slot);
+    if (rc) return rc;
+  }
+  const VariantOps* v = h->var;
+  const int lds = v->lds_bytes + g_lds_pad;
+  if (!h->grid_waves) {   // resident wavefronts of the handle's kernel variant (queried once)
+    int per_cu = 0;
+    hipDeviceProp_t prop;
+    HIP_TRY(h, hipGetDeviceProperties(&prop, h->device));
+    HIP_TRY(h, v->occupancy(&per_cu, lds));
+    h->grid_waves = per_cu > 0 ? per_cu * prop.multiProcessorCount : 4096;
+  }
+  // one decision per game and launch: two waves per slot measured best; many decisions per game: exactly the resident waves
+  int grid = rounds > 1 ? h->grid_waves : 2 * h->grid_waves;
+  if (const char* e = getenv("MONSOON_GRID")) grid = atoi(e);
+  // the persistent form needs a wavefront for every one of its POP_PARTS ranges
+  const int pers = (g_persistent && grid < n && grid >= POP_PARTS) ? 1 : 0;
+  if (!pers) grid = n;
+  v->play(grid, lds, h->stream, h->b, n, max_turns, rounds, write_scores, pers, h->parity);
+  h->parity ^= 1;
+  HIP_TRY(h, hipGetLastError());
+  if (timed) HIP_TRY(h, hipEventRecord(h->ev_pool[slot].second, h->stream));
   return MONSOON_OK;
 }
 
@@ -1195,7 +890,19 @@ int monsoon_decide_round_dev(monsoon_t* h) {
     h->err = "monsoon_decide_round_dev: upload weights and assign players first";
     return MONSOON_ERR_STATE;
   }
-  return launch_decide(h, h->n, 0x7fff, 0, true);
+  return launch_play(h, h->n, 0x7fff, 1, 0, true);
+}
+
+// `rounds` decisions of every loaded game in one launch: a game's record stays in LDS from its first to its last decision
+// of the call (asynchronous on the handle's stream, like monsoon_decide_round_dev = rounds 1).
+int monsoon_play_rounds_dev(monsoon_t* h, int32_t rounds) {
+  int rc = check_ready(h);
+  if (rc) return rc;
+  if (rounds <= 0 || !h->b.weights) {
+    h->err = "monsoon_play_rounds_dev: rounds must be positive; upload weights and assign players first";
+    return rounds <= 0 ? MONSOON_ERR_ARG : MONSOON_ERR_STATE;
+  }
+  return launch_play(h, h->n, 0x7fff, rounds, 0, true);
 }
 
 int monsoon_sync(monsoon_t* h) {
@@ -1218,14 +925,14 @@ int monsoon_decide(monsoon_t* h, const double* weights, uint8_t* out_action, dou
     p1[i] = 2 * i;
     p2[i] = 2 * i + 1;
   }
-  rc = monsoon_assign_players(h, p1.data(), p2.data());
+  rc = assign_players(h, p1.data(), p2.data(), 0);
   if (rc) return rc;
   if (out_scores) {
     if (!h->b.scores) HIP_TRY(h, hipMalloc(&h->b.scores, (size_t)h->cfg.max_games * MONSOON_NUM_ACTIONS * 8));
     size_t cnt = (size_t)n * MONSOON_NUM_ACTIONS;
     hipLaunchKernelGGL(k_clear_scores, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, h->stream, h->b.scores, cnt);
   }
-  rc = launch_decide(h, n, 0x7fff, out_scores ? 1 : 0, false);
+  rc = launch_play(h, n, 0x7fff, 1, out_scores ? 1 : 0, false);
   if (rc) return rc;
   std::vector<GameMeta> meta(n);
   HIP_TRY(h, hipMemcpyAsync(meta.data(), h->b.meta, (size_t)n * sizeof(GameMeta), hipMemcpyDeviceToHost, h->stream));
@@ -1241,19 +948,44 @@ int monsoon_decide(monsoon_t* h, const double* weights, uint8_t* out_action, dou
 int monsoon_rollout(monsoon_t* h, const double* weights, int32_t n_individuals, const monsoon_match* matches,
                     int32_t n_matches, const uint8_t* deck_pairs, int32_t n_decks, int32_t max_turns,
                     int32_t* out_counts, int8_t* out_results, int32_t* out_steps) {
-  if (!h || !weights || !matches || !deck_pairs || !out_counts || n_matches <= 0 || n_individuals <= 0 || max_turns <= 0 ||
-      max_turns > 30000)
+  if (!h) return MONSOON_ERR_ARG;
+  if (!weights || !matches || !deck_pairs || !out_counts || n_matches <= 0 || n_individuals <= 0 || n_decks <= 0 || max_turns <= 0 ||
+      max_turns > 30000) {
+    h->err = "monsoon_rollout: bad argument";
     return MONSOON_ERR_ARG;
-  int rc = monsoon_upload_weights(h, weights, n_individuals);
+  }
+  // The whole schedule and every deck are checked before anything is loaded or launched.
+  for (int i = 0; i < n_matches; i++) {
+    const monsoon_match& mm = matches[i];
+    if (mm.p1 < 0 || mm.p1 >= n_individuals || mm.p2 < 0 || mm.p2 >= n_individuals || mm.deck >= (uint32_t)n_decks) {
+      h->err = "monsoon_rollout: schedule entry " + std::to_string(i) + " out of range";
+      return MONSOON_ERR_ARG;
+    }
+  }
+  int rc = check_decks(h, deck_pairs, (size_t)n_decks * 24, "monsoon_rollout");
   if (rc) return rc;
+  rc = monsoon_upload_weights(h, weights, n_individuals);
+  if (rc) return rc;
+  // result buffers live in the handle: grown when a larger schedule arrives, never freed per call
+  if ((size_t)n_individuals > h->counts_cap) {
+    if (h->d_counts) HIP_TRY(h, hipFree(h->d_counts));
+    h->d_counts = nullptr;
+    h->counts_cap = 0;
+    HIP_TRY(h, hipMalloc(&h->d_counts, (size_t)n_individuals * 12));
+    h->counts_cap = (size_t)n_individuals;
+  }
+  if ((size_t)n_matches > h->matches_cap) {
+    if (h->d_results) HIP_TRY(h, hipFree(h->d_results));
+    if (h->d_steps) HIP_TRY(h, hipFree(h->d_steps));
+    h->d_results = nullptr;
+    h->d_steps = nullptr;
+    h->matches_cap = 0;
+    HIP_TRY(h, hipMalloc(&h->d_results, (size_t)n_matches));
+    HIP_TRY(h, hipMalloc(&h->d_steps, (size_t)n_matches * 4));
+    h->matches_cap = (size_t)n_matches;
+  }
+  HIP_TRY(h, hipMemsetAsync(h->d_counts, 0, (size_t)n_individuals * 12, h->stream));
   int cap = h->cfg.max_games;
-  int32_t* d_counts = nullptr;
-  int8_t* d_results = nullptr;
-  int32_t* d_steps = nullptr;
-  HIP_TRY(h, hipMalloc(&d_counts, (size_t)n_individuals * 12));
-  HIP_TRY(h, hipMemset(d_counts, 0, (size_t)n_individuals * 12));
-  HIP_TRY(h, hipMalloc(&d_results, (size_t)n_matches));
-  HIP_TRY(h, hipMalloc(&d_steps, (size_t)n_matches * 4));
   std::vector<uint32_t> seeds;
   std::vector<uint8_t> decks;
   std::vector<int32_t> p1, p2;
@@ -1265,84 +997,57 @@ int monsoon_rollout(monsoon_t* h, const double* weights, int32_t n_individuals, 
     p2.resize(n);
     for (int i = 0; i < n; i++) {
       const monsoon_match& mm = matches[base + i];
-      if (mm.p1 < 0 || mm.p1 >= n_individuals || mm.p2 < 0 || mm.p2 >= n_individuals || (int)mm.deck >= n_decks) {
-        h->err = "monsoon_rollout: schedule entry out of range";
-        hipFree(d_counts); hipFree(d_results); hipFree(d_steps);
-        return MONSOON_ERR_ARG;
-      }
       seeds[i] = mm.seed;
       memcpy(&decks[(size_t)i * 24], deck_pairs + (size_t)mm.deck * 24, 24);
       p1[i] = mm.p1;
       p2[i] = mm.p2;
     }
     rc = monsoon_reset(h, n, seeds.data(), decks.data(), nullptr);
-    if (!rc) rc = monsoon_assign_players(h, p1.data(), p2.data());
-    if (rc) {
-      hipFree(d_counts); hipFree(d_results); hipFree(d_steps);
-      return rc;
-    }
-    hipLaunchKernelGGL(k_set_match, dim3((n + 255) / 256), dim3(256), 0, h->stream, h->b, n, base);
-    // max_turns decision rounds + one closing round that turns "still running" into a result.
-    // Every 16 rounds the live count is read back so that finished batches stop early.
-    for (int round = 0; round <= max_turns; round++) {
-      rc = launch_decide(h, n, max_turns, 0, true);
-      if (rc) break;
-      if ((round & 15) == 15) {
-        int live = 0;
-        HIP_TRY(h, hipMemsetAsync(h->d_int, 0, 4, h->stream));
-        hipLaunchKernelGGL(k_count_live, dim3((n + 255) / 256), dim3(256), 0, h->stream, h->b, n, h->d_int);
-        HIP_TRY(h, hipMemcpyAsync(&live, h->d_int, 4, hipMemcpyDeviceToHost, h->stream));
-        HIP_TRY(h, hipStreamSynchronize(h->stream));
-        drain_timing(h);
-        if (live == 0) break;
-      }
-    }
-    if (rc) {
-      hipFree(d_counts); hipFree(d_results); hipFree(d_steps);
-      return rc;
-    }
-    hipLaunchKernelGGL(k_collect, dim3((n + 255) / 256), dim3(256), 0, h->stream, h->b, n, d_counts, d_results, d_steps);
+    if (!rc) rc = assign_players(h, p1.data(), p2.data(), base);
+    if (rc) return rc;
+    // one launch plays the whole batch to the end
+    rc = launch_play(h, n, max_turns, max_turns + 1, 0, true);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_collect, dim3((n + 255) / 256), dim3(256), 0, h->stream, h->b, n, h->d_counts, h->d_results, h->d_steps);
     HIP_TRY(h, hipGetLastError());
     HIP_TRY(h, hipStreamSynchronize(h->stream));
-    drain_timing(h);
+    rc = drain_timing(h);
+    if (rc) return rc;
   }
   std::vector<int32_t> counts((size_t)n_individuals * 3);
-  HIP_TRY(h, hipMemcpy(counts.data(), d_counts, counts.size() * 4, hipMemcpyDeviceToHost));
+  HIP_TRY(h, hipMemcpy(counts.data(), h->d_counts, counts.size() * 4, hipMemcpyDeviceToHost));
   for (size_t i = 0; i < counts.size(); i++) out_counts[i] += counts[i];
-  if (out_results) HIP_TRY(h, hipMemcpy(out_results, d_results, (size_t)n_matches, hipMemcpyDeviceToHost));
-  if (out_steps) HIP_TRY(h, hipMemcpy(out_steps, d_steps, (size_t)n_matches * 4, hipMemcpyDeviceToHost));
-  hipFree(d_counts);
-  hipFree(d_results);
-  hipFree(d_steps);
+  if (out_results) HIP_TRY(h, hipMemcpy(out_results, h->d_results, (size_t)n_matches, hipMemcpyDeviceToHost));
+  if (out_steps) HIP_TRY(h, hipMemcpy(out_steps, h->d_steps, (size_t)n_matches * 4, hipMemcpyDeviceToHost));
   return MONSOON_OK;
 }
 
 // current statistics of the loaded games (see k_stats)
-static int reduce_stats(monsoon_t* h, unsigned long long cur[5]) {
-  for (int i = 0; i < 5; i++) cur[i] = 0;
+static int reduce_stats(monsoon_t* h, unsigned long long cur[ST_N]) {
+  for (int i = 0; i < ST_N; i++) cur[i] = 0;
   if (h->n <= 0) return MONSOON_OK;
-  HIP_TRY(h, hipMemsetAsync(h->b.stats, 0, 5 * sizeof(unsigned long long), h->stream));
+  HIP_TRY(h, hipMemsetAsync(h->b.stats, 0, ST_N * sizeof(unsigned long long), h->stream));
   int blocks = (h->n + 255) / 256;
   if (blocks > 256) blocks = 256;
   hipLaunchKernelGGL(k_stats, dim3(blocks), dim3(256), 0, h->stream, h->b, h->n, h->b.stats);
   HIP_TRY(h, hipGetLastError());
-  HIP_TRY(h, hipMemcpyAsync(cur, h->b.stats, 5 * sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(h, hipMemcpyAsync(cur, h->b.stats, ST_N * sizeof(unsigned long long), hipMemcpyDeviceToHost, h->stream));
   HIP_TRY(h, hipStreamSynchronize(h->stream));
   return MONSOON_OK;
 }
-static int total_stats(monsoon_t* h, unsigned long long tot[5]) {
-  unsigned long long cur[5];
+static int total_stats(monsoon_t* h, unsigned long long tot[ST_N]) {
+  unsigned long long cur[ST_N];
   int rc = reduce_stats(h, cur);
   if (rc) return rc;
-  for (int i = 0; i < 5; i++) tot[i] = h->st_acc[i] + cur[i] - h->st_base[i];
+  for (int i = 0; i < ST_N; i++) tot[i] = h->st_acc[i] + cur[i] - h->st_base[i];
   return MONSOON_OK;
 }
 // the loaded games are about to be replaced: keep what they contributed
 static int fold_stats(monsoon_t* h) {
-  unsigned long long tot[5];
+  unsigned long long tot[ST_N];
   int rc = total_stats(h, tot);
   if (rc) return rc;
-  for (int i = 0; i < 5; i++) {
+  for (int i = 0; i < ST_N; i++) {
     h->st_acc[i] = tot[i];
     h->st_base[i] = 0;
   }
@@ -1352,7 +1057,7 @@ static int fold_stats(monsoon_t* h) {
 int monsoon_get_stats(monsoon_t* h, monsoon_stats* out) {
   if (!h || !out) return MONSOON_ERR_ARG;
   HIP_TRY(h, hipSetDevice(h->device));
-  unsigned long long s[5];
+  unsigned long long s[ST_N];
   int rc = total_stats(h, s);
   if (rc) return rc;
   out->lookahead_steps = s[ST_LOOKAHEAD];
@@ -1360,6 +1065,7 @@ int monsoon_get_stats(monsoon_t* h, monsoon_stats* out) {
   out->games_finished = s[ST_FINISHED];
   out->faults = s[ST_FAULTS];
   out->capacity_faults = s[ST_CAPFAULTS];
+  out->lookahead_capacity_faults = s[ST_LACAPFAULTS];
   return MONSOON_OK;
 }
 
@@ -1422,10 +1128,10 @@ int monsoon_reset_stats(monsoon_t* h) {
   HIP_TRY(h, hipStreamSynchronize(h->stream));
   drain_timing(h);
   {
-    unsigned long long cur[5];
+    unsigned long long cur[ST_N];
     int rc = reduce_stats(h, cur);
     if (rc) return rc;
-    for (int i = 0; i < 5; i++) {
+    for (int i = 0; i < ST_N; i++) {
       h->st_acc[i] = 0;
       h->st_base[i] = cur[i];
     }

@@ -150,6 +150,26 @@ static const CardInfo g_cards[NUM_CARDS] = {
 #include "card_table.inc"
 };
 
+// Card.weight values: wtab[k] = f^k(1), f(w) = w * 1.6 + 100 with both operations rounded separately, exactly as the
+// reference's Python floats compute them (player.py:31,57-59).  Constant-evaluated: no contraction, round to nearest.
+struct WeightTable {
+  double v[256];
+};
+constexpr WeightTable make_weight_table() {
+  WeightTable t{};
+  double w = 1.0;
+  for (int i = 0; i < 256; i++) {
+    t.v[i] = w;
+    double m = w * 1.6;
+    w = m + 100.0;
+  }
+  return t;
+}
+#if defined(__HIPCC__)
+__device__ __constant__
+#endif
+static const WeightTable g_wtab = make_weight_table();
+
 // Card indices used by name in rules.h (sorted-id order; checked against card_ids.json by tests).
 #include "card_names.inc"
 

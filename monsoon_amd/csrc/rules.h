@@ -213,15 +213,14 @@ struct Engine {
   MSB_HD MSB_INL int pl_hand_n(int o) const { return m.ld8g(pg(o) + (P_HAND_N >> 4), P_HAND_N & 15); }
   MSB_HD MSB_INL int pl_deck_n(int o) const { return m.ld8g(pg(o) + (P_DECK_N >> 4), P_DECK_N & 15); }
   // ---- hand / deck lists ---------------------------------------------------------------------
-  // hand_ref/deck_ref: byte offset of the card-instance record {card, cost, flags, x} at a list position;
-  // deck_wref: offset of that card's weight.  Standard record: values stored in place.  Extended record:
-  // positions hold object ids into the player's instance table (state.h).
+  // hand_ref/deck_ref: byte offset of the card-instance record {card, cost, flags, x} at a list position.
+  // Standard record: values stored in place.  Extended record: positions hold object ids into the player's
+  // instance table (state.h).
 #if defined(MSB_EXT) && MSB_EXT
   MSB_HD MSB_INL int hand_id(int o, int i) const { return m.ld8(pl(o, P_HAND + i)); }
   MSB_HD MSB_INL int deck_id(int o, int i) const { return m.ld8(pl(o, P_DECK + i)); }
   MSB_HD MSB_INL int hand_ref(int o, int i) const { return pl(o, P_INST + 4 * hand_id(o, i)); }
   MSB_HD MSB_INL int deck_ref(int o, int i) const { return pl(o, P_INST + 4 * deck_id(o, i)); }
-  MSB_HD MSB_INL int deck_wref(int o, int i) const { return pl(o, P_WEIGHT + 8 * deck_id(o, i)); }
   // a free object id: referenced by neither list
   MSB_HD MSB_NOINLINE int inst_alloc(int o) {
     uint32_t used = 0;
@@ -235,7 +234,6 @@ struct Engine {
 #else
   MSB_HD MSB_INL int hand_ref(int o, int i) const { return pl(o, P_HAND + 4 * i); }
   MSB_HD MSB_INL int deck_ref(int o, int i) const { return pl(o, P_DECK + 4 * i); }
-  MSB_HD MSB_INL int deck_wref(int o, int i) const { return pl(o, P_WEIGHT + 8 * i); }
 #endif
   MSB_HD MSB_INL int hand_card(int o, int i) const { return m.ld8(hand_ref(o, i)); }
   MSB_HD MSB_INL int hand_cost(int o, int i) const { return m.ld8(hand_ref(o, i) + 1); }
@@ -251,14 +249,38 @@ struct Engine {
 #else
   MSB_HD MSB_INL int deck_wslot(int o, int i) const { return i; }
 #endif
-  static_assert(P_WEIGHT % 16 == 0 && E_PATH % 16 == 0, "granule-aligned arrays");
-  MSB_HD MSB_INL double deck_w(int o, int i) const {
-    int k = deck_wslot(o, i);
-    return m.ldfg(pg(o) + P_WEIGHT / 16 + (k >> 1), 8 * (k & 1));
-  }
-  MSB_HD MSB_INL void set_deck_w(int o, int i, double w) {
-    int k = deck_wslot(o, i);
-    m.stfg(pg(o) + P_WEIGHT / 16 + (k >> 1), 8 * (k & 1), w);
+  static_assert(E_PATH % 16 == 0, "granule-aligned arrays");
+  // Card.weight of the card at deck position i = wtab[age] (state.h: the record keeps the age, not the f64)
+  MSB_HD MSB_INL int deck_age(int o, int i) const { return m.ld8(pl(o, P_AGE + deck_wslot(o, i))); }
+  MSB_HD MSB_INL void set_deck_age(int o, int i, int a) { m.st8(pl(o, P_AGE + deck_wslot(o, i)), a); }
+  MSB_HD MSB_INL double deck_w(int o, int i) const { return M::wtab(deck_age(o, i)); }
+  // Player.reweight, player.py:57-59: card.weight = card.weight * 1.6 + 100 for every deck entry = age + 1
+  MSB_HD MSB_INL void reweight(int o) {
+    int n = pl_deck_n(o);
+#if defined(MSB_EXT) && MSB_EXT
+    for (int i = 0; i < n; i++) {   // per list position: an object listed twice ages twice
+      int a = deck_age(o, i);
+      if (a >= AGE_MAX) {
+        set_fault(FAULT_CAP_DECK);
+        return;
+      }
+      set_deck_age(o, i, a + 1);
+    }
+#else
+    static_assert(DECK_CAP == 12, "three age words");
+    for (int w = 0; w < 3; w++) {   // four ages per 32-bit word
+      int k = n - 4 * w;
+      if (k <= 0) break;
+      uint32_t one = k >= 4 ? 0x01010101u : (0x01010101u >> (8 * (4 - k)));
+      uint32_t v = m.ld32(pl(o, P_AGE + 4 * w));
+      uint32_t t = ~v;   // a byte of v is 0xFF <=> that byte of t is 0
+      if (((t - 0x01010101u) & ~t & 0x80808080u) != 0) {
+        set_fault(FAULT_CAP_DECK);
+        return;
+      }
+      m.st32(pl(o, P_AGE + 4 * w), v + one);
+    }
+#endif
   }
   // packed path of entity e (u32[NUM_ENT] after the entity granules)
   MSB_HD MSB_INL uint32_t e_path(int e) const { return m.ld32g(E_PATH / 16 + (e >> 2), 4 * (e & 3)); }
@@ -277,8 +299,9 @@ struct Engine {
 #else
     for (int i = j; i + 1 < n; i++) {
       m.st32(pl(o, P_DECK + 4 * i), m.ld32(pl(o, P_DECK + 4 * (i + 1))));
-      m.stf(pl(o, P_WEIGHT + 8 * i), m.ldf(pl(o, P_WEIGHT + 8 * (i + 1))));
+      m.st8(pl(o, P_AGE + i), m.ld8(pl(o, P_AGE + i + 1)));
     }
+    m.st8(pl(o, P_AGE + n - 1), 0);   // ages beyond the list stay 0 (reweight adds to whole words)
 #endif
     m.st8(pl(o, P_DECK_N), n - 1);
   }
@@ -325,7 +348,7 @@ struct Engine {
     m.st8(pl(o, P_DECK + n), (int)h);
 #else
     m.st32(pl(o, P_DECK + 4 * n), h);
-    m.stf(pl(o, P_WEIGHT + 8 * n), 1.0);
+    m.st8(pl(o, P_AGE + n), 0);
 #endif
     m.st8(pl(o, P_DECK_N), n + 1);
   }
@@ -342,16 +365,16 @@ struct Engine {
     if (fault()) return;
     m.st8(pl(o, (to_hand ? P_HAND : P_DECK) + n), id);
     rec = pl(o, P_INST + 4 * id);
-    wrec = pl(o, P_WEIGHT + 8 * id);
+    wrec = pl(o, P_AGE + id);
 #else
     rec = pl(o, (to_hand ? P_HAND : P_DECK) + 4 * n);
-    if (!to_hand) wrec = pl(o, P_WEIGHT + 8 * n);
+    if (!to_hand) wrec = pl(o, P_AGE + n);
 #endif
     m.st8(rec, card);
     m.st8(rec + 1, cost);
     m.st8(rec + 2, fl);
     m.st8(rec + 3, x);
-    if (wrec >= 0) m.stf(wrec, 1.0);
+    if (wrec >= 0) m.st8(wrec, 0);   // weight = 1
     m.st8(pl(o, to_hand ? P_HAND_N : P_DECK_N), n + 1);
   }
 
@@ -1392,7 +1415,7 @@ struct Engine {
         set_fault(FAULT_PY_EXCEPTION);
         return;
       }
-      set_deck_w(o, idx, 1.0);             // choice.weight = 1
+      set_deck_age(o, idx, 0);             // choice.weight = 1
       hand_push_from_deck(o, idx);         // self.hand.append(choice)
       if (fault()) return;
       int j = first_equal(o, false, idx);  // self.deck.remove(choice): first EQUAL element
@@ -1407,8 +1430,8 @@ struct Engine {
   }
   // Player.discard, player.py:57-66 (reweight: w*1.6+100 for every deck card)
   MSB_HD MSB_INL void discard(int o, int hand_index) {
-    int n = pl_deck_n(o);
-    for (int i = 0; i < n; i++) set_deck_w(o, i, deck_w(o, i) * 1.6 + 100);   // per list position
+    reweight(o);
+    if (fault()) return;
     uint32_t target = hand_handle(o, hand_index);
     int fl = hand_flags(o, hand_index);
     int j = first_equal(o, true, hand_index);   // hand.remove(target): first equal
@@ -1800,9 +1823,7 @@ struct Engine {
         d[i] = d[j];
         d[j] = tmp;
       }
-      double w = 1.0;
-      for (int i = 0; i < DECK_SIZE; i++) {
-        if (i > 0) w = w * 1.6 + 100;
+      for (int i = 0; i < DECK_SIZE; i++) {   // weights 1, f(1), f(f(1)), ... (player.py:29-31): age = position
 #if defined(MSB_EXT) && MSB_EXT
         m.st8(pl(o, P_DECK + i), i);   // object i sits at deck position i
 #endif
@@ -1812,7 +1833,7 @@ struct Engine {
         m.st8(r + 1, g_cards[d[i]].cost);
         m.st8(r + 2, (g_cards[d[i]].ff ? CF_FF : 0) | CF_XBASE | (g_cards[d[i]].kind == KIND_SPELL ? CF_SPELL : 0));
         m.st8(r + 3, g_cards[d[i]].strength);
-        set_deck_w(o, i, w);
+        set_deck_age(o, i, i);
       }
       m.st8(pl(o, P_DECK_N), DECK_SIZE);
       fill_hand(o);

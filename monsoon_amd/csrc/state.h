@@ -81,15 +81,27 @@ constexpr int INST_CAP = 32;
 constexpr int P_HAND = 12;                       // HAND_CAP x u8 instance id
 constexpr int P_DECK = P_HAND + HAND_CAP;        // DECK_CAP x u8 instance id
 constexpr int P_INST = (P_DECK + DECK_CAP + 3) & ~3;          // INST_CAP x {card, cost, flags, x}
-constexpr int P_WEIGHT = (P_INST + 4 * INST_CAP + 7) & ~7;    // INST_CAP x f64 (Card.weight)
-constexpr int PL_SIZE = P_WEIGHT + 8 * INST_CAP;
+constexpr int P_AGE = P_INST + 4 * INST_CAP;                  // INST_CAP x u8 weight age (Card.weight = wtab[age], see below)
+constexpr int PL_SIZE = (P_AGE + INST_CAP + 15) & ~15;
 #else
 constexpr int P_HAND = 12;                      // HAND_CAP x {card, cost, flags, x}
 constexpr int P_DECK = P_HAND + 4 * HAND_CAP;   // DECK_CAP x {card, cost, flags, x}
-constexpr int P_WEIGHT = (P_DECK + 4 * DECK_CAP + 7) & ~7;  // DECK_CAP x f64 (weight of the card at that deck position)
-constexpr int PL_SIZE = P_WEIGHT + 8 * DECK_CAP;
+constexpr int P_AGE = P_DECK + 4 * DECK_CAP;    // DECK_CAP x u8 weight age of the card at that deck position
+constexpr int PL_SIZE = (P_AGE + DECK_CAP + 15) & ~15;
 #endif
-static_assert((OFF_PL % 8) == 0 && (PL_SIZE % 8) == 0, "f64 alignment");
+static_assert((OFF_PL % 16) == 0 && (PL_SIZE % 16) == 0 && (P_AGE % 4) == 0, "granule / word alignment");
+// Card.weight is never stored.  Every weight the reference can hold is f^k(1) with f(w) = w * 1.6 + 100 (player.py:31
+// initial chain, :50 "choice.weight = 1", :57-59 reweight, cards/ua20.py:30 and cards/b305.py:41 "weight = 1"), so the
+// record keeps the integer k ("age", one byte) and the f64 value comes from a table built with the same two rounded
+// operations (msb_base.h g_wtab).  Player.reweight becomes a byte increment per deck entry.
+constexpr int AGE_MAX = 255;
+constexpr int WT_LDS_N = 32;     // table entries the kernels keep in LDS (older cards read the constant table)
+#if defined(MSB_PROF) && MSB_PROF
+constexpr int WT_LDS = 928;      // behind the function-scope counters of the profiling build (msb_base.h)
+#else
+constexpr int WT_LDS = 16;       // LDS address 0 is avoided (the null LDS pointer)
+#endif
+constexpr int LDS_RECORDS = WT_LDS + 8 * WT_LDS_N;   // first LDS byte the kernels may use for records
 // card-instance flags (hand/deck entries {card, cost, flags, x}).  b305 puts the on-board structure OBJECT
 // back into the hand (cards/b305.py:40-45): such an entry aliases entity slot x while that entity is
 // on the board (CF_ALIAS) and keeps its last strength in x afterwards (CF_STR).  Both kinds have a
@@ -154,6 +166,7 @@ struct FlatMem {
   MSB_HD MSB_INL void st32g(int g, int k, uint32_t v) { st32(g * 16 + k, v); }
   MSB_HD MSB_INL double ldfg(int g, int k) const { return ldf(g * 16 + k); }
   MSB_HD MSB_INL void stfg(int g, int k, double v) { stf(g * 16 + k, v); }
+  MSB_HD MSB_INL static double wtab(int age) { return g_wtab.v[age & AGE_MAX]; }
 };
 
 #if defined(__HIPCC__)
@@ -161,6 +174,17 @@ struct FlatMem {
 // global_load/global_store (HBM) instead of flat_* instructions behind non-inlined calls.
 #define MSB_AS_LDS __attribute__((address_space(3)))
 #define MSB_AS_GLB __attribute__((address_space(1)))
+// weight table lookup of the LDS accessors: the first WT_LDS_N entries sit at LDS address WT_LDS (every kernel that
+// runs the rules core fills them, lds_init_wtab), older cards read the constant table
+MSB_HD MSB_INL double lds_wtab(int age) {
+  if (age < WT_LDS_N) return *(MSB_AS_LDS const double*)(uintptr_t)(WT_LDS + 8 * age);
+  return g_wtab.v[age & AGE_MAX];
+}
+MSB_HD MSB_INL void lds_init_wtab() {   // call with all threads of the workgroup, before any engine code
+  for (int i = (int)__builtin_amdgcn_workitem_id_x(); i < WT_LDS_N; i += (int)__builtin_amdgcn_workgroup_size_x())
+    *(MSB_AS_LDS double*)(uintptr_t)(WT_LDS + 8 * i) = g_wtab.v[i];
+  __syncthreads();
+}
 // LDS image of one record, interleaved across the lanes of a wave in 16-BYTE granules: granule c of
 // lane l sits at (c*LANES + l)*16.  A lane's record is copied 16 bytes at a time (ds_read_b128 /
 // ds_write_b128, conflict-free: consecutive lanes touch consecutive 16-byte slots), f64 weights are one
@@ -202,6 +226,7 @@ struct LaneMem {   // this lane's private record among LANES interleaved ones
   MSB_HD MSB_INL static void st32g(int g, int k, uint32_t v) { *(MSB_AS_LDS uint32_t*)gb(g, k) = v; }
   MSB_HD MSB_INL static double ldfg(int g, int k) { return *(MSB_AS_LDS const double*)gb(g, k); }
   MSB_HD MSB_INL static void stfg(int g, int k, double v) { *(MSB_AS_LDS double*)gb(g, k) = v; }
+  MSB_HD MSB_INL static double wtab(int age) { return lds_wtab(age); }
 };
 template <int BASE>
 struct SharedMem {   // one contiguous record read by every lane of the wave (LDS broadcast)
@@ -228,6 +253,7 @@ struct SharedMem {   // one contiguous record read by every lane of the wave (LD
   MSB_HD MSB_INL static void st32g(int g, int k, uint32_t v) { st32(g * 16 + k, v); }
   MSB_HD MSB_INL static double ldfg(int g, int k) { return ldf(g * 16 + k); }
   MSB_HD MSB_INL static void stfg(int g, int k, double v) { stf(g * 16 + k, v); }
+  MSB_HD MSB_INL static double wtab(int age) { return lds_wtab(age); }
 };
 #endif
 

@@ -13,7 +13,9 @@ def _ptr(a):
 
 class BatchEngine:
     def __init__(self, max_games, device=0, lanes_per_game=0, stack_bytes=0, extended=False):
-        """extended=True loads the build with the larger per-game record (decks holding ua20 / b005)."""
+        """extended=True loads the build with the larger per-game record (decks holding ua20 / b005).
+        lanes_per_game selects a hot-kernel variant of the build (0 = default); a value the build does not hold is
+        refused."""
         self.lib = _lib.load(extended)
         self.extended = extended
         self.h = ctypes.c_void_p()
@@ -123,6 +125,25 @@ class BatchEngine:
         self._ck(self.lib.monsoon_state_export(self.h, i, _ptr(buf), ctypes.byref(ln)), "monsoon_state_export")
         return buf[:ln.value].tobytes()
 
+    def variant(self):
+        """(candidate lanes per game, waves per SIMD) of the hot kernel this handle runs."""
+        u, w = ctypes.c_int32(), ctypes.c_int32()
+        self._ck(self.lib.monsoon_variant(self.h, ctypes.byref(u), ctypes.byref(w)), "monsoon_variant")
+        return u.value, w.value
+
+    def save_state(self, i):
+        """copy.deepcopy of game i (evo/game_adapter.py:280-287): the complete device state as an opaque blob."""
+        buf = np.zeros(self.lib.monsoon_state_blob_bytes(), dtype=np.uint8)
+        self._ck(self.lib.monsoon_state_save(self.h, i, _ptr(buf), len(buf)), "monsoon_state_save")
+        return buf.tobytes()
+
+    def load_state(self, i, blob):
+        """Put a blob from save_state (any handle of the same build) into slot i; i == n appends a game."""
+        buf = np.frombuffer(blob, dtype=np.uint8)
+        self._ck(self.lib.monsoon_state_load(self.h, i, _ptr(buf), len(buf)), "monsoon_state_load")
+        if i == self.n:
+            self.n = i + 1
+
     def debug_raw(self, i):
         buf = np.zeros(4096, dtype=np.uint8)
         ln = ctypes.c_int32()
@@ -178,6 +199,10 @@ class BatchEngine:
 
     def decide_round(self):
         self._ck(self.lib.monsoon_decide_round_dev(self.h), "monsoon_decide_round_dev")
+
+    def play_rounds(self, rounds):
+        """`rounds` decisions of every loaded game in one launch (asynchronous; sync() waits)."""
+        self._ck(self.lib.monsoon_play_rounds_dev(self.h, rounds), "monsoon_play_rounds_dev")
 
     def sync(self):
         self._ck(self.lib.monsoon_sync(self.h), "monsoon_sync")

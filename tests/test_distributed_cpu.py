@@ -66,3 +66,39 @@ def test_sharded_evaluation_matches_single_process(tmp_path):
     single_deck = FitnessEvaluator(cfg, _deck_schedule(), rollout_fn=oracle_rollout_fn).evaluate_population(_population(), generation=3)
     assert np.array_equal(d0, d1)
     assert np.array_equal(d0, np.array(single_deck))
+
+
+def _run_bench(args, env_extra):
+    import json
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    env.update(env_extra)
+    p = subprocess.run([sys.executable, os.path.join(repo, "bench.py")] + args, env=env, capture_output=True, text=True, timeout=300)
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    return p.returncode, [json.loads(ln) for ln in lines], p.stderr
+
+
+def test_bench_launcher_starts_the_ranks_itself():
+    """`python bench.py --gpus 2` with no rendezvous in the environment starts two ranks (torch.distributed.run, one
+    process per device) and reports the rank count the all-reduce saw.  CPU ranks: gloo backend and bench.py's
+    stand-in engine (MONSOON_BENCH_FAKE, a test hook) -- what is exercised is the launcher and the rank plumbing."""
+    env = {"MONSOON_BENCH_FAKE": "1", "MONSOON_BENCH_BACKEND": "gloo"}
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        assert k not in os.environ
+    rc, lines, err = _run_bench(["--gpus", "2", "--steps", "3", "--warmup", "1", "--games", "64", "--no-cpu"], env)
+    assert rc == 0, err[-2000:]
+    assert len(lines) == 1   # rank 0 only
+    line = lines[0]
+    assert line["n_gpus"] == 2 and line["ranks"] == {"launched": 2, "in_all_reduce": 2, "backend": "gloo"}
+    assert line["steps"] == 3 and line["scaling"] == "weak"
+    assert line["value"] > 0 and abs(line["lookahead_per_decision"] - 17.0) < 1e-9   # both ranks' counters were summed
+
+
+def test_bench_refuses_more_gpus_than_the_machine_has():
+    """On a machine with fewer GPUs than --gpus (this container has none) the bench fails loudly instead of printing a
+    line with a smaller n_gpus."""
+    rc, lines, err = _run_bench(["--gpus", "2", "--steps", "1", "--warmup", "0", "--no-cpu"], {})
+    assert rc != 0 and lines == []
+    assert "refusing" in err

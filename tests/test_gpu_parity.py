@@ -187,12 +187,14 @@ def test_heuristic_two_weight_vectors_vs_reference(engines, gold):
             assert best[k] == g["best"][i] and hashes[k] == g["hash"][i], (k, t)
 
 
-@pytest.mark.parametrize("lanes", [16, 32, 64])
+@pytest.mark.parametrize("lanes", [4, 8, 16, 32, 64])
 def test_rollout_vs_oracle_2048_games(engines, lanes):
-    """All lane configurations (16 forces the multi-pass + replay path) give the oracle's games."""
+    """Every hot-kernel variant of the build (candidate lanes per game; 4 and 8 lanes force several passes per decision
+    and the parked-best path) gives the oracle's games, played to the end inside one launch."""
     n = 2048
     deck = deck_indices("N12M")
     eng = engines(n, lanes)
+    assert eng.variant()[0] == lanes   # the variant asked for is the one that runs: no silent substitute
     matches = np.zeros(n, dtype=[("p1", "<i4"), ("p2", "<i4"), ("seed", "<u4"), ("deck", "<u4")])
     matches["seed"] = np.arange(n) + 100000
     counts, results, steps = eng.rollout(W0[None], matches, np.stack([deck, deck])[None], 200, want_results=True)
@@ -206,7 +208,97 @@ def test_rollout_vs_oracle_2048_games(engines, lanes):
     assert np.array_equal(hashes, ohash)
     assert counts[0, 2] == n and counts[0, 0] == int((ores == 0).sum()) and counts[0, 1] == int((ores == -1).sum())
     st = eng.stats()
-    assert st["capacity_faults"] == 0
+    assert st["capacity_faults"] == 0 and st["lookahead_capacity_faults"] == 0
+
+
+def test_unknown_kernel_variant_is_refused():
+    from monsoon_amd._lib import MonsoonError
+    from monsoon_amd.engine import BatchEngine
+    with pytest.raises(MonsoonError):
+        BatchEngine(64, lanes_per_game=24)   # not a variant of the build (monsoon_amd/csrc/variants.def)
+    with pytest.raises(MonsoonError):
+        BatchEngine(64, lanes_per_game=2)
+
+
+def test_small_batches_play_every_game(engines):
+    """Batches smaller than the persistent grid's 8 ranges, and one-game tails of a batched rollout: every game is
+    decided / played (a range without a wavefront once left games unplayed)."""
+    from monsoon_amd.engine import BatchEngine
+    deck = deck_indices("N12M")
+    for n in range(1, 10):
+        eng = BatchEngine(n)
+        eng.reset(np.arange(n, dtype=np.uint32) + 500, np.stack([deck, deck]))
+        orc = oracle_lib.Oracle(n)
+        for i in range(n):
+            orc.reset(i, 500 + i, deck, deck)
+        for t in range(3):
+            action, best = eng.decide(W0)
+            hashes = eng.state_hash()
+            for i in range(n):
+                a, sc, _ = orc.decide(i, W0)
+                assert a == action[i] and best[i] == sc[a], (n, t, i)
+                orc.step(i, a)
+                assert orc.canon_hash(i) == int(hashes[i]), (n, t, i)
+        eng.close()
+    # rollout of max_games + 1 matches: the second batch holds a single game
+    cap = 24
+    eng = BatchEngine(cap)
+    m = np.zeros(cap + 1, dtype=[("p1", "<i4"), ("p2", "<i4"), ("seed", "<u4"), ("deck", "<u4")])
+    m["seed"] = 900 + np.arange(cap + 1)
+    counts, results, steps = eng.rollout(W0[None], m, np.stack([deck, deck])[None], 60, want_results=True)
+    orc = oracle_lib.Oracle(1)
+    for i in range(cap + 1):
+        orc.reset(0, 900 + i, deck, deck)
+        r = orc.rollout(0, W0, W0, 60)
+        assert (r["result"], r["steps"]) == (results[i], steps[i]), i
+    assert counts[0, 2] == cap + 1
+    eng.close()
+
+
+def test_play_rounds_equals_single_decision_rounds():
+    """monsoon_play_rounds_dev(k): k decisions per game inside one launch (record resident in LDS, "before" features
+    carried from decision to decision) leave exactly the states, cursors and counters of k single-decision launches."""
+    from monsoon_amd.engine import BatchEngine
+    n = 3000
+    deck = deck_indices("N12M")
+    a, bq = BatchEngine(n), BatchEngine(n)
+    for e in (a, bq):
+        e.reset(np.arange(n, dtype=np.uint32) + 31, np.stack([deck, deck]))
+        e.upload_weights(W0.reshape(1, 10))
+        e.assign_players(np.zeros(n, dtype=np.int32), np.zeros(n, dtype=np.int32))
+    for k in (1, 7, 40, 3):
+        a.play_rounds(k)
+        for _ in range(k):
+            bq.decide_round()
+        a.sync()
+        bq.sync()
+        assert np.array_equal(a.state_hash(), bq.state_hash()), k
+        assert a.stats() == bq.stats(), k
+    assert a.export(17) == bq.export(17)
+    a.close()
+    bq.close()
+
+
+def test_state_save_load_round_trip_and_clone(engines):
+    """monsoon_state_save / monsoon_state_load: export -> import -> export is byte-identical for every state of a game,
+    and a clone loaded into another handle continues exactly like the original (copy.deepcopy incl. the stream)."""
+    from monsoon_amd.engine import BatchEngine
+    deck = deck_indices("N12M")
+    a = BatchEngine(4)
+    bq = BatchEngine(4)
+    a.reset(np.array([11, 12, 13, 14], dtype=np.uint32), np.stack([deck, deck]))
+    bq.reset(np.array([1, 2, 3, 4], dtype=np.uint32), np.stack([deck, deck]))
+    for t in range(40):
+        blob = a.save_state(2)
+        bq.load_state(1, blob)
+        assert bq.save_state(1) == blob, t
+        assert bq.export(1) == a.export(2), t
+        act_a, best_a = a.decide(W0)
+        act_b, best_b = bq.decide(W0)
+        assert act_a[2] == act_b[1] and best_a[2] == best_b[1] or (np.isnan(best_a[2]) and np.isnan(best_b[1])), t
+        assert a.export(2) == bq.export(1), t
+    a.close()
+    bq.close()
 
 
 def test_rollout_schedule_two_weight_vectors(engines):
@@ -337,12 +429,19 @@ def test_observation_tensor_view_on_device(engines):
     eng = engines(256)
     deck = deck_indices("N12M")
     eng.reset(np.arange(200, dtype=np.uint32), np.stack([deck, deck]))
+    orc = oracle_lib.Oracle(200)
+    for k in range(200):
+        orc.reset(k, k, deck, deck)
     for _ in range(5):
-        eng.decide(W0)
-    host, raises = eng.observe()
+        action, _ = eng.decide(W0)
+        for k in range(200):
+            orc.step(k, int(action[k]))
     dev, draises = eng.observe_torch()
     assert dev.is_cuda and dev.shape == (200, 27, 5, 4) and dev.dtype == torch.int32
-    assert np.array_equal(dev.cpu().numpy(), host) and np.array_equal(draises.cpu().numpy(), raises)
+    got = dev.cpu().numpy()
+    for k in range(200):   # against the CPU replay's observation of the same state, game by game
+        assert np.array_equal(got[k], orc.observe(k)), k
+    assert not draises.cpu().numpy().any()
 
 
 def test_rollout_rejects_empty_and_out_of_range_schedules(engines):
