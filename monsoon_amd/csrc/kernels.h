@@ -392,6 +392,7 @@ __device__ void play_game(const DevBuffers& b, const int g, const int lane, int 
         new_pos -= MT_N;
         wave_refill(b, g, cur, (MSB_AS_LDS uint32_t*)priv, lane);   // the used-up block becomes the new "next" block
         cur ^= 1;
+        if (lane == 0) pe.rng_block_advance();
       }
       meta.rng = new_pos | ((uint32_t)cur << 16);
       if (lane == 0) attach_rng(pe, b, g, meta.rng);

@@ -76,7 +76,7 @@ __global__ void __launch_bounds__(64) k_seed(DevBuffers b, int n, const uint32_t
   wave_refill(b, g, 1, t, lane);
 }
 
-__global__ void __launch_bounds__(64) k_init(DevBuffers b, int n, const uint8_t* decks, const uint8_t* factions) {
+__global__ void __launch_bounds__(64) k_init(DevBuffers b, int n, const uint8_t* decks, const uint8_t* factions, const uint32_t* seeds) {
   API_GAME_INDEX();
   ApiEngine e;
   GameMeta m = b.meta[g];
@@ -87,7 +87,8 @@ __global__ void __launch_bounds__(64) k_init(DevBuffers b, int n, const uint8_t*
     d0[i] = decks[(size_t)g * 24 + i];
     d1[i] = decks[(size_t)g * 24 + 12 + i];
   }
-  e.init_game(d0, d1, factions[2 * g], factions[2 * g + 1]);
+  e.init_game(d0, d1, factions[2 * g], factions[2 * g + 1], seeds[g]);
+  if (e.rng_pos() >= (uint32_t)MT_N) e.rng_block_advance();
   lane_commit_rng(b, g, m, e.rng_pos());
   m.result = -2;
   m.fault = (uint8_t)e.fault();
@@ -133,6 +134,7 @@ __global__ void __launch_bounds__(64) k_step(DevBuffers b, int n, const uint8_t*
   reward[g] = (int8_t)(rd & 1);
   done[g] = (uint8_t)((rd >> 1) & 1);
   fault[g] = (uint8_t)e.fault();
+  if (e.rng_pos() >= (uint32_t)MT_N) e.rng_block_advance();
   lane_commit_rng(b, g, m, e.rng_pos());
   m.steps++;
   m.last_action = (uint8_t)a;
@@ -151,6 +153,10 @@ __global__ void __launch_bounds__(64) k_expert(DevBuffers b, int n, uint8_t* out
   int a = e.expert_action();
   out_action[g] = (uint8_t)a;
   fault[g] = (uint8_t)e.fault();
+  if (e.rng_pos() >= (uint32_t)MT_N) {   // the record counts its stream blocks (extended build: state.h X_RNGBLK)
+    e.rng_block_advance();
+    api_store(b.state + (size_t)g * SW);
+  }
   lane_commit_rng(b, g, m, e.rng_pos());
   b.meta[g] = m;
 }
@@ -495,7 +501,11 @@ int monsoon_create(const monsoon_config* cfg, monsoon_t** out) {
   memset(&h->b, 0, sizeof(h->b));
   h->cfg = *cfg;
   h->var = var;
+#if defined(MSB_EXT) && MSB_EXT
+  if (h->cfg.stack_bytes <= 0) h->cfg.stack_bytes = 32768;   // MAX_DEPTH 64 (rules.h)
+#else
   if (h->cfg.stack_bytes <= 0) h->cfg.stack_bytes = 16384;
+#endif
   h->device = cfg->device;
   memset(h->st_acc, 0, sizeof(h->st_acc));
   memset(h->st_base, 0, sizeof(h->st_base));
@@ -532,7 +542,7 @@ static int check_ready(monsoon_t* h) {
 
 static int launch_reset(monsoon_t* h, int n) {
   hipLaunchKernelGGL(k_seed, dim3(n), dim3(64), 0, h->stream, h->b, n, h->d_seeds);
-  hipLaunchKernelGGL(k_init, dim3((n + API_LANES - 1) / API_LANES), dim3(64), API_LDS_BYTES, h->stream, h->b, n, h->d_decks, h->d_factions);
+  hipLaunchKernelGGL(k_init, dim3((n + API_LANES - 1) / API_LANES), dim3(64), API_LDS_BYTES, h->stream, h->b, n, h->d_decks, h->d_factions, h->d_seeds);
   HIP_TRY(h, hipGetLastError());
   return MONSOON_OK;
 }

@@ -15,6 +15,17 @@
 #include "pyset.h"
 #include "state.h"
 
+#if defined(MSB_FAULT_TRACE) && !defined(__HIPCC__)
+#include <execinfo.h>
+#include <stdio.h>
+static inline void msb_fault_trace(int code) {
+  void* bt[24];
+  int n = backtrace(bt, 24);
+  fprintf(stderr, "set_fault(%d)\n", code);
+  backtrace_symbols_fd(bt, n, 2);
+}
+#endif
+
 namespace msb {
 
 struct P {
@@ -53,6 +64,20 @@ struct PList {
     if (i < 10)
       w[0] = (w[0] & msk) | bits;
     else if (i < 20)
+      w[1] = (w[1] & msk) | bits;
+    else
+      w[2] = (w[2] & msk) | bits;
+  }
+  // the same three words as 24 one-byte entries (entity slot ids)
+  MSB_HD MSB_INL int get8(int i) const {
+    unsigned long long x = i < 8 ? w[0] : (i < 16 ? w[1] : w[2]);
+    return (int)((x >> (8 * (i & 7))) & 0xffull);
+  }
+  MSB_HD MSB_INL void set8(int i, int v) {
+    unsigned long long msk = ~(0xffull << (8 * (i & 7))), bits = (unsigned long long)(v & 0xff) << (8 * (i & 7));
+    if (i < 8)
+      w[0] = (w[0] & msk) | bits;
+    else if (i < 16)
       w[1] = (w[1] & msk) | bits;
     else
       w[2] = (w[2] & msk) | bits;
@@ -115,7 +140,7 @@ MSB_HD MSB_INL Tgt mk_tgt(const TargetSpec& s) {
 
 // Results of Board.at (board.py:58-65)
 constexpr int AT_NONE = -1;
-constexpr int AT_PLAYER = 64;   // + PlayerOrder
+constexpr int AT_PLAYER = 256;  // + PlayerOrder (above every entity slot id)
 
 enum : int { SH_FRONT, SH_BEHIND, SH_SIDE, SH_ROW, SH_COLUMN, SH_BORDERING, SH_SURROUNDING };
 
@@ -149,6 +174,7 @@ struct Engine {
 
   // ---- numpy legacy RandomState draws over the record's stream window (mt19937.h) ----------------
   MSB_HD MSB_INL uint32_t rng_next_u32() {
+    if (REM_LISTS && ctx() != 0) return world_rng_next();   // an entity of a frozen world draws from THAT world's stream copy
     uint32_t i = (uint32_t)m.ld16(H_RNGPOS) & 0xffffu;
     if (i < (uint32_t)(2 * MT_N)) {
       uint64_t blk = m.ld64(i < (uint32_t)MT_N ? H_RNGCUR : H_RNGNXT);
@@ -195,6 +221,9 @@ struct Engine {
   // ------------------------------------------------------------------------------------------
   MSB_HD MSB_INL int fault() const { return m.ld8(H_FAULT); }
   MSB_HD MSB_INL void set_fault(int code) {
+#if defined(MSB_FAULT_TRACE) && !defined(__HIPCC__)
+    msb_fault_trace(code);   // debugging aid of the host build (oracle/Makefile: make trace)
+#endif
     if (m.ld8(H_FAULT) == 0) m.st8(H_FAULT, code);
   }
   MSB_HD MSB_INL int local() const { return m.ld8(H_TOPLAY); }     // order of board.local
@@ -223,11 +252,12 @@ struct Engine {
   MSB_HD MSB_INL int deck_ref(int o, int i) const { return pl(o, P_INST + 4 * deck_id(o, i)); }
   // a free object id: referenced by neither list
   MSB_HD MSB_NOINLINE int inst_alloc(int o) {
-    uint32_t used = 0;
-    for (int i = 0; i < pl_hand_n(o); i++) used |= 1u << hand_id(o, i);
-    for (int i = 0; i < pl_deck_n(o); i++) used |= 1u << deck_id(o, i);
+    static_assert(INST_CAP <= 64, "one 64-bit word of object ids");
+    uint64_t used = 0;
+    for (int i = 0; i < pl_hand_n(o); i++) used |= 1ull << hand_id(o, i);
+    for (int i = 0; i < pl_deck_n(o); i++) used |= 1ull << deck_id(o, i);
     for (int k = 0; k < INST_CAP; k++)
-      if (!(used & (1u << k))) return k;
+      if (!(used & (1ull << k))) return k;
     set_fault(FAULT_CAP_DECK);
     return 0;
   }
@@ -470,17 +500,99 @@ struct Engine {
     if (e >= 0) e_set_pos(e, p);
   }
 
-  // A free entity slot: not on the board and not referenced since the step began.
+  // A free entity slot: not on the board and not referenced since the step began.  The standard record keeps the
+  // set in one 32-bit word; the extended record (up to 128 slots) in four.
+  struct Bits {
+    uint64_t lo, hi;
+    MSB_HD MSB_INL bool has(int i) const { return ((i < 64 ? lo >> i : hi >> (i - 64)) & 1ull) != 0; }
+    MSB_HD MSB_INL void add(int i) {
+      if (i < 64) lo |= 1ull << i;
+      else hi |= 1ull << (i - 64);
+    }
+    MSB_HD MSB_INL bool any() const { return (lo | hi) != 0; }
+    MSB_HD MSB_INL int pop() {   // lowest member, removed
+      if (lo) {
+        int i = __builtin_ctzll(lo);
+        lo &= lo - 1;
+        return i;
+      }
+      int i = __builtin_ctzll(hi);
+      hi &= hi - 1;
+      return 64 + i;
+    }
+  };
+  MSB_HD MSB_INL Bits used_mask() const {
+    Bits u{m.ld32(H_USED), 0};
+    if (NUM_ENT > 32) {
+      u.lo |= (uint64_t)m.ld32(X_USED_HI) << 32;
+      u.hi = (uint64_t)m.ld32(X_USED_HI + 4) | ((uint64_t)m.ld32(X_USED_HI + 8) << 32);
+    }
+    return u;
+  }
+  MSB_HD MSB_INL void set_used_mask(Bits u) {
+    m.st32(H_USED, (uint32_t)u.lo);
+    if (NUM_ENT > 32) {
+      m.st32(X_USED_HI, (uint32_t)(u.lo >> 32));
+      m.st32(X_USED_HI + 4, (uint32_t)u.hi);
+      m.st32(X_USED_HI + 8, (uint32_t)(u.hi >> 32));
+    }
+  }
   MSB_HD MSB_INL int alloc_entity() {
-    uint32_t used = m.ld32(H_USED);
-    uint32_t free_mask = ~used & ((1u << NUM_ENT) - 1u);
-    if (free_mask == 0) {
+    if (NUM_ENT <= 32) {
+      uint32_t used = m.ld32(H_USED);
+      uint32_t free_mask = ~used & ((1u << (NUM_ENT & 31)) - 1u);
+      if (free_mask == 0) {
+        set_fault(FAULT_CAPACITY);
+        return 0;
+      }
+      int e = __builtin_ctz(free_mask);   // lowest free slot (a search loop unrolls into 28 nested exec masks)
+      m.st32(H_USED, used | (1u << e));
+      return e;
+    }
+    int e = alloc_entity_ext();
+    if (e < 0 && take_back_world_copies()) e = alloc_entity_ext();   // the real game comes first: empty a snapshot
+    if (e < 0) {
       set_fault(FAULT_CAPACITY);
       return 0;
     }
-    int e = __builtin_ctz(free_mask);   // lowest free slot (a search loop unrolls into 28 nested exec masks)
-    m.st32(H_USED, used | (1u << e));
     return e;
+  }
+  MSB_HD MSB_INL int alloc_entity_ext() {   // -1 = no free slot
+    static_assert(NUM_ENT <= 32 || (NUM_ENT % 32 == 0 && NUM_ENT <= 128), "extended record: up to four words of slot bits");
+    for (int w = 0; w < NUM_ENT / 32; w++) {
+      const int off = w == 0 ? H_USED : X_USED_HI + 4 * (w - 1);
+      uint32_t used = m.ld32(off);
+      if (used != 0xffffffffu) {
+        int b = __builtin_ctz(~used);
+        m.st32(off, used | (1u << b));
+        return 32 * w + b;
+      }
+    }
+    return -1;
+  }
+  // Free the private copies of one frozen world (not the one the engine is acting in); that world becomes partial.
+  MSB_HD MSB_NOINLINE bool take_back_world_copies() {
+    const int c = ctx();
+    for (int w = WORLD_CAP; w >= 1; w--) {
+      const int o = world_off(w);
+      if (w == c || !m.ld8(o + W_USED)) continue;
+      bool any = false;
+      Bits u = used_mask();
+      for (int t = 0; t < 20; t++) {
+        int h = m.ld8(o + W_BOARD + t);
+        if (h >= NUM_ENT || m.ld8(E_HOME + h) != (HOME_COPY | w)) continue;
+        m.st8(o + W_BOARD + t, SLOT_MISSING);
+        if (h < 64) u.lo &= ~(1ull << h);
+        else u.hi &= ~(1ull << (h - 64));
+        any = true;
+      }
+      if (any) {
+        set_used_mask(u);
+        m.st8(o + W_PARTIAL, 1);
+        return true;
+      }
+    }
+    return false;
   }
   // Called at the start of every step: everything not on the board is garbage in the reference
   // (no live Python reference survives a step).
@@ -501,15 +613,21 @@ struct Engine {
   MSB_HD MSB_INL uint32_t empty_mask() const { return ~occ_mask() & 0xFFFFFu; }
   MSB_HD MSB_INL void begin_step() {
     MSB_SCOPE(PS_BEGIN_STEP);
-    // one shift per tile, no compare: an empty tile (0xFF) sets bit 31, which is not an entity slot
-    static_assert((SLOT_NONE & 31) >= NUM_ENT, "the empty marker must map outside the slot bits");
-    uint32_t used = 0;
+    // one shift per tile, no compare: an empty tile (0xFF) sets the top bit, which is not an entity slot
+    static_assert((SLOT_NONE & 31) >= 28 && NUM_ENT <= 128, "the empty marker must map outside the slot bits");
+    Bits used{0, 0};
     for (int y = 0; y < 5; y++) {
       uint32_t row = board_row(y);
-      for (int x = 0; x < 4; x++) used |= 1u << ((row >> (8 * x)) & 31u);
+      if (NUM_ENT <= 32) {
+        for (int x = 0; x < 4; x++) used.lo |= 1u << ((row >> (8 * x)) & 31u);
+      } else {
+        for (int x = 0; x < 4; x++) {
+          uint32_t sl = (row >> (8 * x)) & 0xffu;
+          if (sl != (uint32_t)SLOT_NONE) used.add((int)(sl & 127u));
+        }
+      }
     }
-    used &= (1u << NUM_ENT) - 1u;
-    m.st32(H_USED, used);
+    if (NUM_ENT <= 32) used.lo &= (1ull << (NUM_ENT & 31)) - 1ull;
     // a hand/deck entry aliasing an entity that has left the board keeps that object's last strength
     if (m.ld8(H_OBSFAULT) & GF_ALIAS) {
       for (int o = 0; o < 2; o++) {
@@ -519,7 +637,7 @@ struct Engine {
           int fl = m.ld8(off + 2);
           if (!(fl & CF_ALIAS)) continue;
           int slot = m.ld8(off + 3);
-          if (used & (1u << slot)) continue;
+          if (used.has(slot)) continue;
           int str = e_str(slot);
           if (str < 0 || str > 255) {
             set_fault(FAULT_CAP_INST);
@@ -530,7 +648,8 @@ struct Engine {
         }
       }
     }
-    if (REM_LISTS) rem_collect(used);
+    if (REM_LISTS) used = rem_collect(used);
+    set_used_mask(used);
     m.st8(H_DEPTH, 0);
   }
   MSB_HD MSB_INL int new_entity(int card, int owner, int strength, int movement, bool ff) {
@@ -548,92 +667,293 @@ struct Engine {
                    0u, (uint32_t)(strength & 0xffff) << 16, (uint32_t)kind_byte(card) << 24};
     m.st128g(eg(e), g);
     e_set_path(e, 0);
-    if (REM_LISTS) m.st8(E_REM + e, REM_NONE);
+    if (REM_LISTS) {
+      m.st8(E_REM + e, REM_NONE);
+      m.st8(E_HOME + e, ctx());   // token.player = <a player of the world the spawning entity lives in>
+    }
     return e;
   }
 
-  // ---- b005's remembered deep copies (extended record only) ---------------------------------
-  MSB_HD MSB_INL int rem_off(int list) const { return OFF_REM + list * REM_LIST_BYTES; }
-  MSB_HD MSB_INL int rem_rec(int list, int i) const { return rem_off(list) + 4 + i * REM_REC; }
+  // ------------------------------------------------------------------------------------------
+  // Worlds (extended record only; state.h).  ctx = the world whose board / players / trigger stack / stream the
+  // record's own fields currently hold: an entity method of the reference reaches them through self.player, so it
+  // runs in the world of the entity it is called on (ctx_enter / ctx_leave around every such method).
+  // ------------------------------------------------------------------------------------------
+  MSB_HD MSB_INL int ctx() const { return REM_LISTS ? m.ld8(X_CTX) : 0; }
+  MSB_HD MSB_INL int e_home(int e) const { return REM_LISTS ? (m.ld8(E_HOME + e) & 0x7f) : 0; }
+  MSB_HD MSB_INL static int world_off(int w) { return OFF_WORLD + (w - 1) * WORLD_BYTES; }
+  MSB_HD MSB_INL void swap8(int a, int b) {
+    int x = m.ld8(a), y = m.ld8(b);
+    m.st8(a, y);
+    m.st8(b, x);
+  }
+  MSB_HD MSB_INL void swap32(int a, int b) {
+    uint32_t x = m.ld32(a), y = m.ld32(b);
+    m.st32(a, y);
+    m.st32(b, x);
+  }
+  // exchange the record's own world fields with storage w
+  MSB_HD MSB_NOINLINE void swap_world(int w) {
+    const int o = world_off(w);
+    static_assert(OFF_BOARD % 4 == 0 && OFF_TRIG % 4 == 0 && OFF_WORLD % 4 == 0, "word-wise swaps");
+    for (int k = 0; k < 5; k++) swap32(OFF_BOARD + 4 * k, o + W_BOARD + 4 * k);
+    for (int k = 0; k < 5; k++) swap32(OFF_TRIG + 4 * k, o + W_TRIG + 4 * k);
+    swap8(H_TOPLAY, o + W_TOPLAY);
+    swap8(H_TRIG_N, o + W_TRIG_N);
+    swap8(H_RESOLVING, o + W_RESOLVING);
+    swap8(H_PHASE, o + W_PHASE);
+    swap8(H_CP, o + W_CP);
+    for (int p = 0; p < 2; p++) {
+      swap8(pl(p, P_FRONT), o + W_FRONT + p);
+      int x = m.ld16(pl(p, P_BASE)), y = m.ld16(o + W_BASE + 2 * p);
+      m.st16(pl(p, P_BASE), y);
+      m.st16(o + W_BASE + 2 * p, x);
+    }
+  }
+  // Invariant: with ctx = c != 0 the record's fields hold world c and storage c holds the real game's.
+  MSB_HD MSB_INL void switch_ctx(int w) {
+    int c = ctx();
+    if (c == w) return;
+    if (w == WORLD_LOST || (w != 0 && m.ld8(world_off(w) + W_PARTIAL))) {
+      set_fault(FAULT_CAPACITY);   // the snapshot this entity lives in could not be kept (state.h: slots are a cache)
+      return;
+    }
+    if (c) swap_world(c);
+    if (w) swap_world(w);
+    m.st8(X_CTX, w);
+  }
+  // enter the world of entity e; returns the world to come back to (-1 = no switch happened)
+  MSB_HD MSB_INL int ctx_enter(int e) {
+    if (!REM_LISTS) return -1;
+    int h = e_home(e), c = ctx();
+    if (h == c) return -1;
+    switch_ctx(h);
+    return c;
+  }
+  MSB_HD MSB_INL void ctx_leave(int saved) {
+    if (REM_LISTS && saved >= 0 && !fault()) switch_ctx(saved);
+  }
+  // one draw of the current world's stream copy: an absolute position in the game's stream
+  MSB_HD MSB_NOINLINE uint32_t world_rng_next() {
+    const int o = world_off(ctx());
+    uint32_t abs = m.ld32(o + W_RNG);
+    uint32_t blk = abs / (uint32_t)MT_N, idx = abs % (uint32_t)MT_N, cur = (uint32_t)m.ld16(X_RNGBLK) & 0xffffu;
+    m.st32(o + W_RNG, abs + 1);
+    uint64_t p = 0;
+    if (blk == cur) p = m.ld64(H_RNGCUR);
+    else if (blk == cur + 1) p = m.ld64(H_RNGNXT);
+    else if (blk < cur) return mt_regen_word(m.ld32(X_SEED), blk, idx);   // that block is no longer resident
+    if (p == 0) {
+      m.st8(H_RNGOVER, 1);
+      return 0;
+    }
+    return ((MSB_RNG_PTR)(uintptr_t)p)[idx];
+  }
+  // output idx of block blk of RandomState(seed), from scratch (rare: a world older than the two resident blocks)
+  MSB_HD MSB_NOINLINE static uint32_t mt_regen_word(uint32_t seed, uint32_t blk, uint32_t idx) {
+    uint32_t mt[MT_N];
+    mt_seed(mt, seed);
+    for (uint32_t b = 0; b <= blk; b++) mt_twist(mt);
+    return mt_temper(mt[idx]);
+  }
+  // the record's stream window moved on by one block (called by whoever commits the cursor)
+  MSB_HD MSB_INL void rng_block_advance() {
+    if (REM_LISTS) m.st16(X_RNGBLK, (int)(((uint32_t)m.ld16(X_RNGBLK) + 1u) & 0xffffu));
+  }
+  MSB_HD MSB_INL void set_seed(uint32_t seed) {
+    if (REM_LISTS) m.st32(X_SEED, seed);
+  }
+
+  // ---- b005's remembered copies (extended record only) -----------------------------------------
+  MSB_HD MSB_INL static int rem_off(int list) { return OFF_REM + list * REM_LIST_BYTES; }
+  MSB_HD MSB_INL int rem_n(int list) const { return m.ld8(rem_off(list)); }
+  MSB_HD MSB_INL int rem_get(int list, int i) const { return m.ld8(rem_off(list) + 4 + i); }
   MSB_HD MSB_INL int rem_alloc() {
     for (int l = 0; l < REM_LISTS; l++)
       if (m.ld8(rem_off(l) + 1) == 0) {
         m.st8(rem_off(l), 0);
         m.st8(rem_off(l) + 1, 1);
-        m.st8(rem_off(l) + 2, 0);
         return l;
       }
     set_fault(FAULT_CAP_REM);
     return REM_NONE;
   }
-  MSB_HD void rem_mark(int list, uint32_t& live) {
-    if (list == REM_NONE || (live & (1u << list))) return;
-    live |= 1u << list;
-    int n = m.ld8(rem_off(list));
-    for (int i = 0; i < n; i++) rem_mark(m.ld8(rem_rec(list, i) + 11), live);
-  }
-  // lists reachable from a b005 on the board survive the step; everything else is garbage
-  MSB_HD MSB_NOINLINE void rem_collect(uint32_t used) {
-    uint32_t live = 0;
-    for (int e = 0; e < NUM_ENT; e++)
-      if (used & (1u << e)) rem_mark(m.ld8(E_REM + e), live);
+  MSB_HD MSB_INL int rem_alloc_soft() {   // REM_LOST instead of a fault
     for (int l = 0; l < REM_LISTS; l++)
-      if (!(live & (1u << l))) m.st8(rem_off(l) + 1, 0);
+      if (m.ld8(rem_off(l) + 1) == 0) {
+        m.st8(rem_off(l), 0);
+        m.st8(rem_off(l) + 1, 1);
+        return l;
+      }
+    return REM_LOST;
   }
-  // copy.deepcopy of a remembered list, nested memories included
-  MSB_HD int rem_deep_copy(int src, int depth) {
-    if (src == REM_NONE) return REM_NONE;
-    if (depth > 6) {
-      set_fault(FAULT_CAP_REM);
-      return REM_NONE;
+  MSB_HD MSB_INL int world_alloc() {
+    for (int w = 1; w <= WORLD_CAP; w++)
+      if (m.ld8(world_off(w) + W_USED) == 0) {
+        m.st8(world_off(w) + W_USED, 1);
+        return w;
+      }
+    return WORLD_LOST;   // no storage: the entities that would live in it are lost to the game unless they never act
+  }
+  // Garbage collection at the start of a step: what the real board reaches survives -- entities on it, the memory
+  // lists of those (and, nested, of the remembered copies), the worlds such entities belong to and everything on a
+  // live world's board or trigger stack.  Returns the set of live entity slots.
+  MSB_HD MSB_NOINLINE Bits rem_collect(Bits used) {
+    Bits todo = used;
+    uint32_t lists = 0, worlds = 0;
+    while (todo.any()) {
+      const int e = todo.pop();
+      const int L = m.ld8(E_REM + e);
+      if (L != REM_NONE && L < REM_LISTS && !((lists >> L) & 1u)) {
+        lists |= 1u << L;
+        int n = rem_n(L);
+        for (int k = 0; k < n; k++) {
+          int r = rem_get(L, k) & 127;
+          if (!used.has(r)) {
+            used.add(r);
+            todo.add(r);
+          }
+        }
+      }
+      const int hb = m.ld8(E_HOME + e);
+      const int H = (hb & HOME_COPY) ? 0 : hb;   // a snapshot's private copy keeps nothing alive by itself
+      if (H != 0 && H <= WORLD_CAP && !((worlds >> H) & 1u)) {
+        worlds |= 1u << H;
+        const int o = world_off(H);
+        int tn = m.ld8(o + W_TRIG_N);
+        for (int t = 0; t < 20 + tn; t++) {
+          int v = t < 20 ? m.ld8(o + W_BOARD + t) : (m.ld8(o + W_TRIG + t - 20) & 0x7f);
+          if (t < 20 && (v == SLOT_NONE || v == SLOT_MISSING)) continue;
+          v &= 127;
+          if (!used.has(v)) {
+            used.add(v);
+            todo.add(v);
+          }
+        }
+      }
     }
-    int dst = rem_alloc();
-    if (fault()) return REM_NONE;
-    int n = m.ld8(rem_off(src));
-    m.st8(rem_off(dst), n);
-    // The reference's deepcopy reaches the whole game through entity.player (card.py:72): entities inside
-    // a NESTED memory keep a copied Player whose board is a frozen duplicate.  Restoring such an entity
-    // makes it act on that phantom board, which this record cannot express: the list is marked and a
-    // restore from it raises FAULT_UNSUPPORTED (needs two adjacent b005 of one owner).
-    m.st8(rem_off(dst) + 2, 1);
-    for (int k = 0; k < n && !fault(); k++) {
-      for (int b = 0; b < REM_REC - 1; b++) m.st8(rem_rec(dst, k) + b, m.ld8(rem_rec(src, k) + b));
-      m.st8(rem_rec(dst, k) + 11, rem_deep_copy(m.ld8(rem_rec(src, k) + 11), depth + 1));
-    }
-    return dst;
+    for (int l = 0; l < REM_LISTS; l++) m.st8(rem_off(l) + 1, (lists >> l) & 1u);
+    for (int w = 1; w <= WORLD_CAP; w++) m.st8(world_off(w) + W_USED, (worlds >> w) & 1u);
+    return used;
   }
-  // deep copy of entity e into record i of `list` (Card.copy, card.py:71-75)
-  MSB_HD MSB_NOINLINE void rem_snapshot(int list, int i, int e) {
-    int r = rem_rec(list, i);
-    m.st8(r + 0, e_card(e));
-    m.st8(r + 1, e_flags(e));
-    m.st8(r + 2, m.ld8g(eg(e), EO_POS));
-    m.st8(r + 3, e_mov(e));
-    for (int s = 0; s < 5; s++) m.st8(r + 4 + s, e_st(e, s));
-    int str = e_str(e);
-    m.st8(r + 9, str & 0xff);
-    m.st8(r + 10, (str >> 8) & 0xff);
-    int nested = rem_deep_copy(m.ld8(E_REM + e), 0);   // a remembered b005 carries a deep copy of its own memory
-    if (fault()) return;
-    m.st8(r + 11, nested);
+  // a new slot with the same attributes as h (path included), no memory of its own, same world
+  MSB_HD MSB_INL int dup_entity(int h, bool may_fail = false) {
+    int c = may_fail ? alloc_entity_ext() : alloc_entity();
+    if (c < 0 || fault()) return c;
+    m.st128g(eg(c), m.ld128g(eg(h)));
+    e_set_path(c, e_path(h));
+    m.st8(E_REM + c, REM_NONE);
+    m.st8(E_HOME + c, m.ld8(E_HOME + h) & 0x7f);
+    return c;
   }
-  // board.set(entity.position, entity) with a remembered copy: a NEW object enters the board
-  MSB_HD MSB_NOINLINE int rem_instantiate(int list, int i) {
-    int r = rem_rec(list, i);
-    if (m.ld8(rem_off(list) + 2)) {
+  // deepcopy of world src as it is now (only called while the record holds the real game, ctx 0).  The entity the
+  // running deepcopy started from keeps its identity inside the snapshot: where src's board holds root_old the
+  // snapshot holds root_new (deepcopy's memo).
+  MSB_HD MSB_NOINLINE int world_snapshot(int src, int root_old, int root_new) {
+    if (ctx() != 0) {
       set_fault(FAULT_UNSUPPORTED);
       return 0;
     }
-    int card = m.ld8(r);
-    int fl = m.ld8(r + 1);
-    int str = (int16_t)(m.ld8(r + 9) | (m.ld8(r + 10) << 8));
-    int e = new_entity(card, fl & EF_OWNER, str, m.ld8(r + 3), (fl & EF_FF) != 0);
-    if (fault()) return e;
-    m.st8g(eg(e), EO_FLAGS, fl);
-    for (int s = 0; s < 5; s++) m.st8g(eg(e), EO_ST + s, m.ld8(r + 4 + s));
-    m.st8(E_REM + e, m.ld8(r + 11));   // the nested memory now belongs to the restored object
-    board_set(tile_p(m.ld8(r + 2)), e);
-    return e;
+    if (src == WORLD_LOST) return WORLD_LOST;
+    const int w = world_alloc();
+    if (w == WORLD_LOST) return w;
+    const int o = world_off(w), so = src ? world_off(src) : 0;
+    m.st8(o + W_PARTIAL, src ? m.ld8(so + W_PARTIAL) : 0);
+    m.st8(o + W_TOPLAY, src ? m.ld8(so + W_TOPLAY) : m.ld8(H_TOPLAY));
+    m.st8(o + W_RESOLVING, src ? m.ld8(so + W_RESOLVING) : m.ld8(H_RESOLVING));
+    m.st8(o + W_PHASE, src ? m.ld8(so + W_PHASE) : m.ld8(H_PHASE));
+    m.st8(o + W_CP, src ? m.ld8(so + W_CP) : m.ld8(H_CP));
+    for (int p = 0; p < 2; p++) {
+      m.st8(o + W_FRONT + p, src ? m.ld8(so + W_FRONT + p) : m.ld8(pl(p, P_FRONT)));
+      m.st16(o + W_BASE + 2 * p, src ? m.ld16(so + W_BASE + 2 * p) : m.ld16(pl(p, P_BASE)));
+    }
+    m.st32(o + W_RNG, src ? m.ld32(so + W_RNG)
+                          : ((uint32_t)m.ld16(X_RNGBLK) & 0xffffu) * (uint32_t)MT_N + ((uint32_t)m.ld16(H_RNGPOS) & 0xffffu));
+    for (int t = 0; t < 20; t++) {
+      int h = src ? m.ld8(so + W_BOARD + t) : board_at(t);
+      int nh = h;   // SLOT_NONE and SLOT_MISSING carry over
+      if (h < NUM_ENT) {
+        if (h == root_old) {
+          nh = root_new;
+        } else if (m.ld8(o + W_PARTIAL)) {
+          nh = SLOT_MISSING;
+        } else {
+          nh = dup_entity(h, true);
+          if (nh < 0) {   // out of slots: the snapshot stays partial (state.h: slots are a cache)
+            nh = SLOT_MISSING;
+            m.st8(o + W_PARTIAL, 1);
+          } else {
+            m.st8(E_HOME + nh, HOME_COPY | w);   // its .player is the snapshot's player; it exists on this board only
+          }
+        }
+      }
+      m.st8(o + W_BOARD + t, nh);
+    }
+    // pending triggers name entity objects: the copies standing on the same tiles (anything else is out of reach)
+    int tn = src ? m.ld8(so + W_TRIG_N) : m.ld8(H_TRIG_N);
+    m.st8(o + W_TRIG_N, tn);
+    for (int i = 0; i < tn; i++) {
+      int v = src ? m.ld8(so + W_TRIG + i) : m.ld8(OFF_TRIG + i);
+      int nv = -1;
+      for (int t = 0; t < 20; t++)
+        if ((src ? m.ld8(so + W_BOARD + t) : board_at(t)) == (v & 0x7f)) nv = m.ld8(o + W_BOARD + t);
+      if (nv < 0 || nv >= NUM_ENT) {
+        m.st8(o + W_PARTIAL, 1);
+        nv = 0;
+      }
+      m.st8(o + W_TRIG + i, nv | (v & 0x80));
+    }
+    return w;
+  }
+  // copy.deepcopy of a memory list (the list object, its entities, their own memories, and -- through entity.player
+  // -- the world each of them belongs to, once per deepcopy call: memo[])
+  MSB_HD int rem_deep_copy(int src, int* memo, int root_old, int root_new, int depth) {
+    if (depth > 4) {
+      set_fault(FAULT_CAP_REM);
+      return REM_NONE;
+    }
+    if (src == REM_LOST) return REM_LOST;
+    int dst = rem_alloc_soft();
+    if (dst == REM_LOST) return REM_LOST;   // no list storage: the copy's memory is lost unless it is never used
+    int n = rem_n(src);
+    m.st8(rem_off(dst), n);
+    for (int k = 0; k < n && !fault(); k++) {
+      int r = rem_get(src, k);
+      int c = dup_entity(r);
+      if (fault()) break;
+      m.st8(rem_off(dst) + 4 + k, c);
+      int H = m.ld8(E_HOME + r) & 0x7f;
+      int nh = WORLD_LOST;
+      if (H != WORLD_LOST) {
+        if (memo[H] < 0) memo[H] = world_snapshot(H, root_old, root_new);
+        if (fault()) break;
+        nh = memo[H];
+      }
+      m.st8(E_HOME + c, nh);
+      int L2 = m.ld8(E_REM + r);
+      if (L2 == REM_LOST || (L2 != REM_NONE && rem_n(L2) > 0)) {
+        int d2 = rem_deep_copy(L2, memo, root_old, root_new, depth + 1);
+        if (fault()) break;
+        m.st8(E_REM + c, d2);
+      }
+    }
+    return dst;
+  }
+  // Card.copy() of the on-board entity e (card.py:71-75): deepcopy, then copied.player = self.player
+  MSB_HD MSB_NOINLINE int rem_copy_entity(int e) {
+    int c = dup_entity(e);   // same world as e: the one attribute that is re-bound
+    if (fault()) return c;
+    int L = m.ld8(E_REM + e);
+    if (L == REM_LOST) {
+      m.st8(E_REM + c, REM_LOST);
+    } else if (L != REM_NONE && rem_n(L) > 0) {
+      int memo[WORLD_CAP + 1];
+      for (int i = 0; i <= WORLD_CAP; i++) memo[i] = -1;
+      int d = rem_deep_copy(L, memo, e, c, 0);
+      if (fault()) return c;
+      m.st8(E_REM + c, d);
+    }
+    return c;
   }
 
   // Board.calculate_front_line, board.py:78-92.  `player` is an order; the reference compares
@@ -922,9 +1242,10 @@ struct Engine {
   // passed in `spell`.  The trailing pop_trigger() is a tail call in the reference, hence a loop.
   MSB_HD MSB_INL void run_ability(int e, int spell, int pos_pk, bool src) {
     MSB_PRECALL();
+    const int sv = e >= 0 ? ctx_enter(e) : -1;   // the wrapper works on self.player.board (card.py:54-60)
     run_ability_impl(e, spell, pos_pk, src);
+    ctx_leave(sv);
     MSB_POSTCALL(PS_RUN_ABILITY);
-    
   }
   MSB_HD MSB_NOINLINE void run_ability_impl(int e, int spell, int pos_pk, bool src) {
     MSB_SCOPE(PS_RUN_ABILITY);
@@ -973,7 +1294,9 @@ struct Engine {
   // Unit.deal_damage unit.py:205-219 / Structure.deal_damage structure.py:52-63
   MSB_HD MSB_INL int entity_deal_damage(int e, int amount, bool pending, bool src) {
     MSB_PRECALL();
+    const int sv = ctx_enter(e);
     int r_ = entity_deal_damage_impl(e, amount, pending, src);
+    ctx_leave(sv);
     MSB_POSTCALL(PS_DEAL_DAMAGE);
     return r_;
   }
@@ -1012,9 +1335,10 @@ struct Engine {
   // Unit.destroy unit.py:221-231 / Structure.destroy structure.py:65-69
   MSB_HD MSB_INL void destroy(int e, bool src) {
     MSB_PRECALL();
+    const int sv = ctx_enter(e);
     destroy_impl(e, src);
+    ctx_leave(sv);
     MSB_POSTCALL(PS_DESTROY);
-    
   }
   MSB_HD MSB_A_DESTROY void destroy_impl(int e, bool src) {
     MSB_SCOPE(PS_DESTROY);
@@ -1071,9 +1395,10 @@ struct Engine {
   // Unit.set_path, unit.py:78-122
   MSB_HD MSB_INL void set_path(int e, bool on_play) {
     MSB_PRECALL();
+    const int sv = ctx_enter(e);
     set_path_impl(e, on_play);
+    ctx_leave(sv);
     MSB_POSTCALL(PS_SET_PATH);
-    
   }
   MSB_HD MSB_A_SETPATH void set_path_impl(int e, bool on_play) {
     MSB_SCOPE(PS_SET_PATH);
@@ -1146,9 +1471,10 @@ struct Engine {
   // Unit.move, unit.py:124-203
   MSB_HD MSB_INL void move(int e) {
     MSB_PRECALL();
+    const int sv = ctx_enter(e);
     move_impl(e);
+    ctx_leave(sv);
     MSB_POSTCALL(PS_MOVE);
-    
   }
   MSB_HD MSB_NOINLINE void move_impl(int e) {
     MSB_SCOPE(PS_MOVE);
@@ -1254,9 +1580,14 @@ struct Engine {
     m.st8g(eg(e), EO_MOV, mv);
   }
   // Unit.command, unit.py:282-289
-  MSB_HD MSB_A_MISC void command(int e) {
-    MSB_SCOPE(PS_COMMAND);
+  MSB_HD MSB_INL void command(int e) {
     if (!need_unit(e)) return;
+    const int sv = ctx_enter(e);
+    command_impl(e);
+    ctx_leave(sv);
+  }
+  MSB_HD MSB_A_MISC void command_impl(int e) {
+    MSB_SCOPE(PS_COMMAND);
     bool ff = e_ff(e);
     e_set_flag(e, EF_FF, true);
     set_path(e, false);
@@ -1271,7 +1602,12 @@ struct Engine {
     set_path(e, e_resolving_play(e));
   }
   // Unit.teleport, unit.py:373-382
-  MSB_HD MSB_A_MISC void teleport(int e, P dest) {
+  MSB_HD MSB_INL void teleport(int e, P dest) {
+    const int sv = ctx_enter(e);
+    teleport_impl(e, dest);
+    ctx_leave(sv);
+  }
+  MSB_HD MSB_A_MISC void teleport_impl(int e, P dest) {
     MSB_SCOPE(PS_TELEPORT);
     if (at(dest) == AT_NONE) {
       board_set(e_pos(e), -1);
@@ -1282,9 +1618,14 @@ struct Engine {
     }
   }
   // Unit.push (away from `from`) unit.py:318-339 and Unit.pull (towards) unit.py:295-316
-  MSB_HD MSB_A_MISC void push_pull(int e, P from, bool is_push) {
-    MSB_SCOPE(PS_PUSH_PULL);
+  MSB_HD MSB_INL void push_pull(int e, P from, bool is_push) {
     if (!need_unit(e)) return;
+    const int sv = ctx_enter(e);
+    push_pull_impl(e, from, is_push);
+    ctx_leave(sv);
+  }
+  MSB_HD MSB_A_MISC void push_pull_impl(int e, P from, bool is_push) {
+    MSB_SCOPE(PS_PUSH_PULL);
     P pos = e_pos(e);
     int dx = 0, dy = 0;
     if (from.y < pos.y)
@@ -1309,7 +1650,12 @@ struct Engine {
     if (pl_front(o) > y) set_pl_front(o, y > 1 ? y : 1);
   }
   // Unit.force_attack, unit.py:341-371
-  MSB_HD MSB_A_MISC void force_attack(int e, P dest) {
+  MSB_HD MSB_INL void force_attack(int e, P dest) {
+    const int sv = ctx_enter(e);
+    force_attack_impl(e, dest);
+    ctx_leave(sv);
+  }
+  MSB_HD MSB_A_MISC void force_attack_impl(int e, P dest) {
     MSB_SCOPE(PS_FORCE_ATTACK);
     P pos = e_pos(e);
     if ((dest.x != pos.x && dest.y != pos.y) || at(dest) == AT_NONE) return;
@@ -1347,7 +1693,12 @@ struct Engine {
   }
   // Unit.respawn unit.py:384-402 / Structure.respawn structure.py:77-89: a fresh object of the same
   // class with the given strength is written onto the tile (whatever was there is overwritten).
-  MSB_HD MSB_A_MISC void respawn(int e, P position, int strength) {
+  MSB_HD MSB_INL void respawn(int e, P position, int strength) {
+    const int sv = ctx_enter(e);
+    respawn_impl(e, position, strength);
+    ctx_leave(sv);
+  }
+  MSB_HD MSB_A_MISC void respawn_impl(int e, P position, int strength) {
     MSB_SCOPE(PS_RESPAWN);
     int c = e_card(e);
     int ne;
@@ -1525,7 +1876,12 @@ struct Engine {
       m.st32(OFF_BOARD + 4 * y, v);
       for (int x = 0; x < 4; x++) {
         uint32_t s = (v >> (8 * x)) & 0xff;
-        if (s != (uint32_t)SLOT_NONE) m.st8g(eg((int)s), EO_POS, y * 4 + x);
+        if (s != (uint32_t)SLOT_NONE) {
+          m.st8g(eg((int)s), EO_POS, y * 4 + x);
+          // board.py:108-115: every on-board entity's .player is re-bound to the board's own players -- an entity that
+          // still belonged to a frozen world (a restored nested b005 memory) joins the real game here
+          if (REM_LISTS) m.st8(E_HOME + (int)s, 0);
+        }
       }
     }
   }
@@ -1547,21 +1903,23 @@ struct Engine {
     int ncp = (ender == local()) ? remote() : local();
     m.st8(H_CP, ncp);
     m.st8(pl(ncp, P_FLAGS), m.ld8(pl(ncp, P_FLAGS)) | 3);
-    // snapshots of entity objects (fact #6): the same packed list type holds the slot ids (< 64)
+    // snapshots of entity objects (fact #6): the slot ids, one byte each, in the words of a second list value
+    PList hs;
+    hs.clear();
     PList snap = get_targets(ncp, mk_tgt(TK_STRUCTURE, TS_FRIENDLY), PK_NONE);
     int ns = snap.n();
-    for (int i = 0; i < ns; i++) snap.set(i, at(snap.at(i)));
+    for (int i = 0; i < ns; i++) hs.set8(i, at(snap.at(i)));
     for (int i = 0; i < ns; i++) {
-      int s = snap.get(i);
+      int s = hs.get8(i);
       // structure.is_at_turn_start: token structures and b001 run the empty base ability
       if (e_card_trigger(s) == TR_TURN_START) run_ability(s, -1, m.ld8g(eg(s), EO_POS) /*unused*/, true);
       if (fault()) return;
     }
     snap = get_targets(ncp, mk_tgt(TK_UNIT, TS_FRIENDLY), PK_NONE);
     ns = snap.n();
-    for (int i = 0; i < ns; i++) snap.set(i, at(snap.at(i)));
+    for (int i = 0; i < ns; i++) hs.set8(i, at(snap.at(i)));
     for (int i = 0; i < ns; i++) {
-      int u = snap.get(i);
+      int u = hs.get8(i);
       set_path(u, false);
       move(u);
       if (fault()) return;
@@ -1788,7 +2146,7 @@ struct Engine {
 
   // Game construction: Stormbound.__init__ / Player.__init__ (games/stormbound.py:293-304,
   // player.py:13-37).  deck0/deck1: 12 card indices in constructor order.
-  MSB_HD MSB_NOINLINE void init_game(const uint8_t* deck0, const uint8_t* deck1, int faction0, int faction1) {
+  MSB_HD MSB_NOINLINE void init_game(const uint8_t* deck0, const uint8_t* deck1, int faction0, int faction1, uint32_t seed = 0) {
     uint64_t rc = m.ld64(H_RNGCUR), rn = m.ld64(H_RNGNXT);
     uint32_t rp = rng_pos();
     for (int w = 0; w < STATE_WORDS; w++) m.st32(4 * w, 0);
@@ -1797,8 +2155,10 @@ struct Engine {
     m.st16(H_RNGPOS, (int)rp);
     for (int t = 0; t < 20; t++) board_put(t, SLOT_NONE);
     for (int e = 0; e < NUM_ENT; e++) m.st8g(eg(e), EO_CARD, CARD_NONE);
-    if (REM_LISTS)
+    if (REM_LISTS) {
       for (int e = 0; e < NUM_ENT; e++) m.st8(E_REM + e, REM_NONE);
+      set_seed(seed);
+    }
     for (int i = 0; i < 4; i++) {
       m.st8(H_HIST + 2 * i, 0xff);
       m.st8(H_HIST + 2 * i + 1, 0xff);

@@ -19,22 +19,53 @@
 
 namespace msb {
 
+#if defined(MSB_EXT) && MSB_EXT
+constexpr int NUM_ENT = 128;  // 20 tiles + transient + b005's remembered copies + the entities of frozen world snapshots
+#else
 constexpr int NUM_ENT = 28;    // 20 tiles + 8 transient (dead / displaced / spawned this step)
+#endif
 constexpr int HAND_CAP = 5;    // 4, transiently 5 (b305 returns itself to hand)
 constexpr int DECK_SIZE = 12;  // cards per deck at construction (games/stormbound.py:295-302)
 // Two builds of the same source.  The standard record holds every card except ua20 and b005; the
 // EXTENDED record (-DMSB_EXT=1: libmonsoon_hip_ext.so / liboracle_ext.so) adds room for ua20's extra
 // single-use deck cards (cards/ua20.py:27-32) and for b005's remembered deep copies (cards/b005.py:14-33).
 #if defined(MSB_EXT) && MSB_EXT
-constexpr int DECK_CAP = 24;
-constexpr int REM_LISTS = 10;  // snapshot lists (one per b005 with a pending memory, nested ones included)
+constexpr int DECK_CAP = 32;
+constexpr int REM_LISTS = 16;  // memory lists (one per b005 with a pending memory, nested ones included)
+constexpr int WORLD_CAP = 8;   // frozen world snapshots alive at once (see below)
 #else
 constexpr int DECK_CAP = 12;
 constexpr int REM_LISTS = 0;
+constexpr int WORLD_CAP = 0;
 #endif
+// b005 (cards/b005.py:14-33) remembers COPIES of its neighbours: a memory list holds up to 8 entity slots that are on
+// no board.  Card.copy() is copy.deepcopy(self) with only the copy's own .player rebound (card.py:71-75), so
+// everything else the copy reaches keeps pointing into a deep copy of the WHOLE GAME as it was at that moment: the
+// entities inside a remembered b005's own memory belong to such a frozen "world" (their .player.board is the
+// snapshot).  Restored later, they sit on the real board but move, fight and trigger on the snapshot until the next
+// Board.flip re-binds every on-board entity to the real players (board.py:108-115).  A world = board + trigger stack
+// + the scalar board/player fields an entity method can reach + its stream position; its entities are ordinary
+// entity slots whose E_HOME names the world.  Entity methods run "in the world of self.player" (rules.h ctx_*).
 constexpr int REM_PER_LIST = 8;   // surrounding tiles
-constexpr int REM_REC = 12;       // card, flags, pos, mov, st[5], strength i16, nested list id
+constexpr int REM_LIST_BYTES = 4 + REM_PER_LIST;   // {n, used, pad2, REM_PER_LIST x entity slot}
 constexpr int REM_NONE = 0xFF;
+constexpr int REM_LOST = 0xFE;    // a remembered copy's own memory found no storage: using it raises FAULT_CAP_REM
+// world storage (WORLD_BYTES each, worlds 1..WORLD_CAP; world 0 = the real game = the record's own fields)
+constexpr int W_BOARD = 0;        // 20 x u8 slot
+constexpr int W_TRIG = 20;        // TRIG_CAP x u8
+constexpr int W_TOPLAY = 40, W_TRIG_N = 41, W_RESOLVING = 42, W_PHASE = 43, W_CP = 44, W_USED = 45, W_FRONT = 46;   // front: 2 x u8
+constexpr int W_BASE = 48;        // 2 x i16
+constexpr int W_RNG = 52;         // u32 absolute position in the game's stream (block * 624 + index)
+constexpr int W_PARTIAL = 56;     // the snapshot is incomplete (entity slots ran out, or were taken back): entering it faults
+constexpr int WORLD_BYTES = 64;
+// Entity slots are a CACHE for the contents of frozen worlds: a world is only ever read if one of its entities is
+// restored to the real board and acts before the next flip -- rare -- so a snapshot that does not fit is not an
+// error by itself.  Its missing tiles hold SLOT_MISSING, a world that found no storage at all is WORLD_LOST, and
+// only ENTERING such a world raises FAULT_CAPACITY.  When the real game needs a slot and none is free, the copies
+// a world owns are taken back (that world becomes partial).
+constexpr int SLOT_MISSING = 0xFE;
+constexpr int WORLD_LOST = 0x7F;
+constexpr int HOME_COPY = 0x80;   // E_HOME bit: the slot is a snapshot's private copy (it exists on that world's board only)
 constexpr int TRIG_CAP = 20;
 constexpr int PATH_CAP = 4;    // max movement among the cards (u069=4; gain_speed gives <= 3)
 constexpr int SLOT_NONE = 0xFF;
@@ -77,7 +108,7 @@ constexpr int P_DECK_N = 10;
 // ua20's duplicate structures make list.remove() take a different (equal) object than the one drawn
 // (player.py:52, structure.py:18-19): the same object can then sit in the hand and in the deck, or twice
 // in the deck, and Player.reweight (player.py:57-59) touches it once per list position.
-constexpr int INST_CAP = 32;
+constexpr int INST_CAP = 40;   // >= HAND_CAP + DECK_CAP distinct objects can be listed
 constexpr int P_HAND = 12;                       // HAND_CAP x u8 instance id
 constexpr int P_DECK = P_HAND + HAND_CAP;        // DECK_CAP x u8 instance id
 constexpr int P_INST = (P_DECK + DECK_CAP + 3) & ~3;          // INST_CAP x {card, cost, flags, x}
@@ -127,9 +158,15 @@ constexpr int EO_KIND = 15;     // u8 static card facts cached at creation: b0 i
 constexpr int EK_UNIT = 1, EK_ABILITY = 2;
 constexpr int E_PATH = OFF_ENT + ENT_SIZE * NUM_ENT;   // u32[NUM_ENT] packed path (PATH_CAP bytes)
 constexpr int E_REM = E_PATH + 4 * NUM_ENT;                       // u8[NUM_ENT]: b005's list id (REM_NONE = [])
-constexpr int OFF_REM = (E_REM + (REM_LISTS ? NUM_ENT : 0) + 3) & ~3; // REM_LISTS x {n, used, pad2, REM_PER_LIST x REM_REC}
-constexpr int REM_LIST_BYTES = 4 + REM_PER_LIST * REM_REC;
-constexpr int STATE_BYTES = (OFF_REM + REM_LISTS * REM_LIST_BYTES + 15) & ~15;   // whole 16-byte granules
+constexpr int E_HOME = E_REM + (REM_LISTS ? NUM_ENT : 0);          // u8[NUM_ENT]: the world the entity's .player belongs to
+constexpr int OFF_REM = (E_HOME + (REM_LISTS ? NUM_ENT : 0) + 3) & ~3;   // REM_LISTS x REM_LIST_BYTES
+constexpr int OFF_WORLD = (OFF_REM + REM_LISTS * REM_LIST_BYTES + 3) & ~3;   // WORLD_CAP x WORLD_BYTES
+// extended-record scalars: X_CTX the world the engine is currently acting in; X_RNGBLK index of the record's current
+// stream block (0 = first 624 outputs); X_SEED the game's seed (a world's old stream position may need a block that
+// is no longer resident); X_USED_HI entity slots 32..127 of H_USED (three more words)
+constexpr int OFF_X = OFF_WORLD + WORLD_CAP * WORLD_BYTES;
+constexpr int X_CTX = OFF_X, X_RNGBLK = OFF_X + 2, X_SEED = OFF_X + 4, X_USED_HI = OFF_X + 8;
+constexpr int STATE_BYTES = (OFF_X + (REM_LISTS ? 20 : 0) + 15) & ~15;   // whole 16-byte granules
 constexpr int STATE_WORDS = STATE_BYTES / 4;
 constexpr int EF_OWNER = 1, EF_FF = 2, EF_RESOLVING_PLAY = 4, EF_SINGLE_USE = 8;
 typedef uint32_t msb_u32x4 __attribute__((vector_size(16)));

@@ -58,6 +58,7 @@ void commit_rng(Game& g, Engine<FlatMem>& e) {
   g.pos = e.rng_pos();
   if (g.pos >= (uint32_t)MT_N) {
     g.pos -= MT_N;
+    e.rng_block_advance();
     int old = g.cur;
     g.cur ^= 1;
     refill(g, old);
@@ -173,7 +174,7 @@ int orc_reset(void* h, int gi, uint32_t seed, const uint8_t* deck0, const uint8_
   g.steps = 0;
   g.lookahead_steps = 0;
   Engine<FlatMem> e = engine(g);
-  e.init_game(deck0, deck1, f0, f1);
+  e.init_game(deck0, deck1, f0, f1, seed);
   commit_rng(g, e);
   return e.fault();
 }
@@ -249,6 +250,19 @@ int orc_have_winner(void* h, int gi) {
   return e.have_winner() ? 1 : 0;
 }
 int orc_to_play(void* h, int gi) { return ((Oracle*)h)->games[gi].st[H_TOPLAY]; }
+// out[0] = entity slots referenced by the last step (highest index + 1), out[1] = memory lists in use, out[2] = worlds in use
+void orc_usage(void* h, int gi, int* out) {
+  Game& g = ((Oracle*)h)->games[gi];
+  Engine<FlatMem> e = engine(g);
+  auto u = e.used_mask();
+  int hi = 0;
+  for (int i = 0; i < NUM_ENT; i++)
+    if (u.has(i)) hi = i + 1;
+  out[0] = hi;
+  out[1] = out[2] = 0;
+  for (int l = 0; l < REM_LISTS; l++) out[1] += g.st[OFF_REM + l * REM_LIST_BYTES + 1] ? 1 : 0;
+  for (int w = 1; w <= WORLD_CAP; w++) out[2] += g.st[OFF_WORLD + (w - 1) * WORLD_BYTES + W_USED] ? 1 : 0;
+}
 
 // scores156: NaN for illegal actions.  Returns the chosen action.
 void orc_lookahead_faults(void* h, int gi, uint8_t* out156) { lookahead_faults(((Oracle*)h)->games[gi], out156); }

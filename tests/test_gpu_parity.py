@@ -55,7 +55,6 @@ def test_random_policy_traces_vs_reference(engines, gold, name):
         orc.reset(k, int(g["seeds"][k]), g["deck0"][k], g["deck1"][k])
     off = g["offsets"]
     lens = (off[1:] - off[:-1]).copy()
-    unsupported = 0
     for t in range(int(lens.max())):
         live = np.nonzero(lens > t)[0]
         masks = eng.legal_mask()
@@ -72,15 +71,10 @@ def test_random_policy_traces_vs_reference(engines, gold, name):
             if g["fault"][k] and t == lens[k] - 1:   # the reference raised on this step
                 assert fault[k] != 0 or raises[k], (k, t)
                 continue
-            if ext and fault[k] == 20 and fo == 20:   # FAULT_UNSUPPORTED (nested b005 memory): flagged on both builds
-                lens[k] = t + 1
-                unsupported += 1
-                continue
             assert fault[k] == 0 and fo == 0, (k, t, fault[k])
             assert hashes[k] == g["hash"][i], (k, t)
             assert (reward[k], done[k]) == (g["reward"][i], g["done"][i]), (k, t)
             assert np.array_equal(obs[k], orc.observe(k)), (k, t)
-    assert unsupported <= 0.05 * n
     if "feat" in g.files:
         feat = eng.features()
         for k in range(n):
@@ -133,27 +127,14 @@ def test_heuristic_selfplay_vs_reference(engines, gold, fixture):
     eng = engines(32, extended=ext)
     eng.reset(g["seeds"], decks)
     off = g["offsets"]
-    # the CPU replay runs alongside only to detect the one flagged behaviour (a look-ahead restoring a nested b005
-    # memory): from that decision on a game is outside what this build reproduces
-    orc = oracle_lib.Oracle(n, extended=True) if ext else None
-    if ext:
-        for k in range(n):
-            orc.reset(k, int(g["seeds"][k]), decks[k][0], decks[k][1])
-    flagged = np.zeros(n, dtype=bool)
     for t in range(int(g["max_turns"])):
-        if ext:
-            for k in range(n):
-                if not flagged[k] and off[k] + t < off[k + 1] and (orc.lookahead_faults(k) == 20).any():
-                    flagged[k] = True
         action, best, scores = eng.decide(g["w0"], want_scores=True)
         hashes = eng.state_hash()
         faults = eng.game_faults()
         for k in range(n):
             i = off[k] + t
-            if i >= off[k + 1] or flagged[k]:
+            if i >= off[k + 1]:
                 continue
-            if ext:
-                orc.step(k, int(g["action"][i]))
             assert action[k] == g["action"][i], (k, t)
             legal = ~np.isnan(scores[k])
             assert int(legal.sum()) == g["nlegal"][i]
@@ -163,6 +144,7 @@ def test_heuristic_selfplay_vs_reference(engines, gold, fixture):
                 assert faults[k] != 0, (k, t)
             else:
                 assert faults[k] == 0 and hashes[k] == g["hash"][i], (k, t)
+    assert eng.stats()["lookahead_capacity_faults"] == 0   # no look-ahead of these games hits a limit of the build
 
 
 def test_heuristic_two_weight_vectors_vs_reference(engines, gold):
@@ -419,8 +401,10 @@ def test_random_deck_rollouts_extended_build_bit_exact(engines):
     _, ores, osteps, ohash = orc.rollout_batch(n, W0, 200, 16)
     assert np.array_equal(results, ores) and np.array_equal(steps, osteps)
     assert np.array_equal(hashes, ohash)
-    # reference-level exceptions are frequent with these decks; build limits must stay rare (nested b005 memory, §2a)
-    assert (faults == 1).sum() > n // 10 and (faults >= 16).sum() < n // 10
+    # reference-level exceptions are frequent with these decks; restored nested b005 memories are reproduced (worlds,
+    # state.h) -- what remains are the capacity limits of the record (entity slots, memory lists, worlds, deck
+    # entries), reported per game and required to stay below 0.5 % here
+    assert (faults == 1).sum() > n // 10 and (faults == 20).sum() == 0 and (faults >= 16).sum() <= n // 200
 
 
 def test_observation_tensor_view_on_device(engines):
