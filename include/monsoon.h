@@ -120,6 +120,15 @@ int32_t monsoon_state_blob_bytes(void);
 int monsoon_state_save(monsoon_t* h, int32_t idx, uint8_t* buf, int32_t buf_bytes);
 int monsoon_state_load(monsoon_t* h, int32_t idx, const uint8_t* buf, int32_t buf_bytes);
 
+/* Diagnostics behind the scenario tests (the reference's own unit tests, test.py:11-147 and the <ID>Test classes, replayed
+ * call by call: tests/scenario_lib.py).  monsoon_debug_build puts game idx (idx <= loaded games) into a described
+ * state: an int32 stream (layout: monsoon_amd/csrc/scenario.inc) and the position of its numpy stream,
+ * RandomState(seed) advanced by stream_pos outputs.  monsoon_debug_op makes ONE call into the engine on that game
+ * (Unit.play, activate_ability, deal_damage, destroy, command, respawn, Board.spawn_token_*, to_next_turn,
+ * Player.play / discard): *fault = the fault code, log = {card, position} of every ability that ran, in order. */
+int monsoon_debug_build(monsoon_t* h, int32_t idx, uint32_t seed, uint32_t stream_pos, const int32_t* state, int32_t n_state, int32_t* fault);
+int monsoon_debug_op(monsoon_t* h, int32_t idx, const int32_t* op, int32_t n_op, int32_t* fault, int32_t* log, int32_t log_cap, int32_t* n_log);
+
 /* Debugging aid: the raw HBM record of game idx (monsoon_amd/csrc/state.h layout); buf must hold 4096 bytes. */
 int monsoon_debug_raw(monsoon_t* h, int32_t idx, uint8_t* buf, int32_t* len);
 

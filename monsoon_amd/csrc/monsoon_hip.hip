@@ -53,12 +53,14 @@ __device__ MSB_INL void api_store(uint32_t* dst) {
   for (int c = 0; c < SG; c++) d4[c] = *(MSB_AS_LDS const u32x4*)ApiMem::b(c * 16);
 }
 
-__global__ void __launch_bounds__(64) k_seed(DevBuffers b, int n, const uint32_t* seeds) {
-  // one wavefront per game: init_genrand is a serial recurrence (lane 0), the two twists are
-  // wave-cooperative
+__global__ void __launch_bounds__(64) k_seed(DevBuffers b, int g0, int n, const uint32_t* seeds) {
+  // one wavefront per game (games g0 .. g0+n-1, seeds[0..n-1]): init_genrand is a serial recurrence (lane 0), the two
+  // twists are wave-cooperative
   __shared__ uint32_t tmp[MT_N];
-  int g = blockIdx.x, lane = threadIdx.x;
-  if (g >= n) return;
+  int lane = threadIdx.x;
+  if ((int)blockIdx.x >= n) return;
+  int g = g0 + blockIdx.x;
+  seeds -= g0;
   MSB_AS_LDS uint32_t* t = (MSB_AS_LDS uint32_t*)tmp;
   if (lane == 0) {
     uint32_t x = seeds[g];
@@ -277,6 +279,52 @@ __global__ void k_collect(DevBuffers b, int n, int32_t* counts, int8_t* results,
   if (!on) return;
   if (results) results[m.match] = (int8_t)r;
   if (steps) steps[m.match] = m.steps;
+}
+
+// monsoon_debug_build / monsoon_debug_op (diagnostics; scenario tests): ONE lane runs scenario.inc on game g.  The
+// engine of this kernel logs the order in which abilities run (TraceLaneMem) -- the product kernels' engines do not.
+constexpr int DBG_TRACE_CAP = 256;
+constexpr int DBG_TRACE = LDS_ORIGIN + SG * 16;                      // u32 count, then {card, position} pairs
+constexpr int DBG_LDS_BYTES = DBG_TRACE + 4 + 8 * DBG_TRACE_CAP;
+typedef Engine<TraceLaneMem<1, LDS_ORIGIN, DBG_TRACE, DBG_TRACE_CAP>> DbgEngine;
+__global__ void __launch_bounds__(64) k_debug(DevBuffers b, int g, int build, uint32_t seed, uint32_t stream_pos, const int32_t* stream,
+                                               int32_t* out /* fault, n_log, pairs... */) {
+  lds_init_wtab();
+  if (threadIdx.x != 0) return;
+  DbgEngine e;
+  MSB_AS_LDS int32_t* tr = (MSB_AS_LDS int32_t*)(uintptr_t)DBG_TRACE;
+  tr[0] = 0;
+  MSB_AS_LDS u32x4* rec = (MSB_AS_LDS u32x4*)(uintptr_t)LDS_ORIGIN;
+  u32x4* grec = (u32x4*)(b.state + (size_t)g * SW);
+  GameMeta m = b.meta[g];
+  int fault = 0;
+  if (build) {
+    // the stream was seeded by k_seed (cursor 0 of block 0): move it to stream_pos
+    m = GameMeta{};
+    m.rng = 0;
+    uint32_t blocks = stream_pos / (uint32_t)MT_N;
+    for (uint32_t k = 0; k < blocks; k++) lane_commit_rng(b, g, m, (uint32_t)MT_N);
+    m.rng = (m.rng & 0x10000u) | (stream_pos % (uint32_t)MT_N);
+    for (int c = 0; c < SG; c++) rec[c] = u32x4{0u, 0u, 0u, 0u};
+    attach_rng(e, b, g, m.rng);
+    if (REM_LISTS) e.m.st16(X_RNGBLK, (int)blocks);
+    e.scn_build(stream, seed);
+    fault = e.fault();
+    m.result = -2;
+    m.last_action = 255;
+  } else {
+    for (int c = 0; c < SG; c++) rec[c] = grec[c];
+    attach_rng(e, b, g, m.rng);
+    fault = e.scn_op(stream);
+    if (e.rng_pos() >= (uint32_t)MT_N) e.rng_block_advance();
+    lane_commit_rng(b, g, m, e.rng_pos());
+  }
+  for (int c = 0; c < SG; c++) grec[c] = rec[c];
+  b.meta[g] = m;
+  out[0] = fault;
+  int n = tr[0];
+  out[1] = n;
+  for (int i = 0; i < 2 * n; i++) out[2 + i] = tr[1 + i];
 }
 
 // monsoon_state_save / monsoon_state_load: one game's complete device state as a flat blob
@@ -541,7 +589,7 @@ static int check_ready(monsoon_t* h) {
 }
 
 static int launch_reset(monsoon_t* h, int n) {
-  hipLaunchKernelGGL(k_seed, dim3(n), dim3(64), 0, h->stream, h->b, n, h->d_seeds);
+  hipLaunchKernelGGL(k_seed, dim3(n), dim3(64), 0, h->stream, h->b, 0, n, h->d_seeds);
   hipLaunchKernelGGL(k_init, dim3((n + API_LANES - 1) / API_LANES), dim3(64), API_LDS_BYTES, h->stream, h->b, n, h->d_decks, h->d_factions, h->d_seeds);
   HIP_TRY(h, hipGetLastError());
   return MONSOON_OK;
@@ -763,6 +811,45 @@ int monsoon_state_load(monsoon_t* h, int32_t idx, const uint8_t* buf, int32_t bu
   HIP_TRY(h, hipStreamSynchronize(h->stream));
   if (idx == h->n) h->n = idx + 1;
   return MONSOON_OK;
+}
+
+// Diagnostics for the scenario tests (tests/scenario_lib.py): build game idx from a state stream / make one engine call.
+static int debug_call(monsoon_t* h, int32_t idx, int build, uint32_t seed, uint32_t stream_pos, const int32_t* stream, int32_t n_stream,
+                      int32_t* fault, int32_t* log, int32_t log_cap, int32_t* n_log) {
+  if (!h || !stream || n_stream <= 0 || n_stream > 3000 || idx < 0 || idx >= h->cfg.max_games || idx > h->n) {
+    if (h) h->err = "monsoon_debug_*: bad argument";
+    return MONSOON_ERR_ARG;
+  }
+  HIP_TRY(h, hipSetDevice(h->device));
+  static_assert(3000 * 4 + (2 + 2 * DBG_TRACE_CAP) * 4 <= 16384, "staging buffer");
+  int32_t* d_stream = (int32_t*)h->d_bytes;
+  int32_t* d_out = d_stream + 3000;
+  HIP_TRY(h, hipMemcpyAsync(d_stream, stream, (size_t)n_stream * 4, hipMemcpyHostToDevice, h->stream));
+  if (build) {
+    HIP_TRY(h, hipMemcpyAsync(h->d_seeds + idx, &seed, 4, hipMemcpyHostToDevice, h->stream));
+    hipLaunchKernelGGL(k_seed, dim3(1), dim3(64), 0, h->stream, h->b, idx, 1, h->d_seeds + idx);
+  }
+  hipLaunchKernelGGL(k_debug, dim3(1), dim3(64), DBG_LDS_BYTES, h->stream, h->b, idx, build, seed, stream_pos, d_stream, d_out);
+  HIP_TRY(h, hipGetLastError());
+  std::vector<int32_t> out(2 + 2 * DBG_TRACE_CAP);
+  HIP_TRY(h, hipMemcpyAsync(out.data(), d_out, out.size() * 4, hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  if (fault) *fault = out[0];
+  int n = out[1] < log_cap ? out[1] : log_cap;
+  if (n_log) *n_log = n;
+  if (log && n > 0) memcpy(log, out.data() + 2, (size_t)n * 8);
+  if (build && idx == h->n) h->n = idx + 1;
+  return MONSOON_OK;
+}
+int monsoon_debug_build(monsoon_t* h, int32_t idx, uint32_t seed, uint32_t stream_pos, const int32_t* state, int32_t n_state, int32_t* fault) {
+  return debug_call(h, idx, 1, seed, stream_pos, state, n_state, fault, nullptr, 0, nullptr);
+}
+int monsoon_debug_op(monsoon_t* h, int32_t idx, const int32_t* op, int32_t n_op, int32_t* fault, int32_t* log, int32_t log_cap, int32_t* n_log) {
+  if (h && idx >= h->n) {
+    h->err = "monsoon_debug_op: no such game";
+    return MONSOON_ERR_ARG;
+  }
+  return debug_call(h, idx, 0, 0, 0, op, n_op, fault, log, log_cap, n_log);
 }
 
 int monsoon_game_faults(monsoon_t* h, uint8_t* out) {

@@ -1257,6 +1257,7 @@ struct Engine {
     m.st8(H_DEPTH, d + 1);
     for (;;) {
       m.st8(H_RESOLVING, 1);
+      M::trace_ability(e >= 0 ? e_card(e) : (spell & 0xff), e >= 0 ? m.ld8g(eg(e), EO_POS) : -1);   // diagnostics hook: nothing in the product
       if (e >= 0) {
         MSB_PRECALL();
         ability_entity(e, pos_pk, src);
@@ -1837,20 +1838,24 @@ struct Engine {
       }
       structure_play(e, position);
     } else {
-      // Spell.play, spell.py:22-24
-      bool go = true;
-      if (ci.tgt.has) {
-        Tgt t = mk_tgt(ci.tgt);
-        PList l = get_targets(cp(), t, PK_NONE);
-        go = has_pos && l.has(position);
-        // `None in [Point...]` evaluates Point.__eq__(None) -> AttributeError when the list is non-empty
-        if (!has_pos && l.n() > 0) {
-          set_fault(FAULT_PY_EXCEPTION);
-          return;
-        }
-      }
-      if (go) run_ability(-1, card | (o << 8), has_pos ? p_pack(position) : PK_NONE, true);
+      spell_play(card, o, position, has_pos);
     }
+  }
+  // Spell.play, spell.py:22-24
+  MSB_HD MSB_INL void spell_play(int card, int o, P position, bool has_pos) {
+    const CardInfo& ci = g_cards[card];
+    bool go = true;
+    if (ci.tgt.has) {
+      Tgt t = mk_tgt(ci.tgt);
+      PList l = get_targets(cp(), t, PK_NONE);
+      go = has_pos && l.has(position);
+      // `None in [Point...]` evaluates Point.__eq__(None) -> AttributeError when the list is non-empty
+      if (!has_pos && l.n() > 0) {
+        set_fault(FAULT_PY_EXCEPTION);
+        return;
+      }
+    }
+    if (go) run_ability(-1, card | (o << 8), has_pos ? p_pack(position) : PK_NONE, true);
   }
   // Player.cycle, player.py:79-81
   MSB_HD MSB_INL void cycle(int o, int hand_index) {
@@ -2206,6 +2211,7 @@ struct Engine {
   // ------------------------------------------------------------------------------------------
 #include "abilities.inc"
 #include "observe.inc"
+#include "scenario.inc"
 };
 
 }  // namespace msb

@@ -172,6 +172,10 @@ constexpr int EF_OWNER = 1, EF_FF = 2, EF_RESOLVING_PLAY = 4, EF_SINGLE_USE = 8;
 typedef uint32_t msb_u32x4 __attribute__((vector_size(16)));
 
 // ---- accessors ----------------------------------------------------------------------------------
+#if !defined(__HIPCC__)
+static thread_local int32_t* msb_trace_log = nullptr;   // {card, position} pairs (FlatMem::trace_ability)
+static thread_local int msb_trace_n = 0, msb_trace_cap = 0;
+#endif
 // Host / flat: the record is a contiguous byte array.
 struct FlatMem {
   uint8_t* p;
@@ -204,6 +208,19 @@ struct FlatMem {
   MSB_HD MSB_INL double ldfg(int g, int k) const { return ldf(g * 16 + k); }
   MSB_HD MSB_INL void stfg(int g, int k, double v) { stf(g * 16 + k, v); }
   MSB_HD MSB_INL static double wtab(int age) { return g_wtab.v[age & AGE_MAX]; }
+  // order in which abilities run (scenario tests): a log the host oracle can switch on; compiled out of device code
+  MSB_HD MSB_INL static void trace_ability(int card, int pos) {
+#if !defined(__HIPCC__)
+    if (msb_trace_log && msb_trace_n < msb_trace_cap) {
+      msb_trace_log[2 * msb_trace_n] = card;
+      msb_trace_log[2 * msb_trace_n + 1] = pos;
+      msb_trace_n++;
+    }
+#else
+    (void)card;
+    (void)pos;
+#endif
+  }
 };
 
 #if defined(__HIPCC__)
@@ -264,6 +281,21 @@ struct LaneMem {   // this lane's private record among LANES interleaved ones
   MSB_HD MSB_INL static double ldfg(int g, int k) { return *(MSB_AS_LDS const double*)gb(g, k); }
   MSB_HD MSB_INL static void stfg(int g, int k, double v) { *(MSB_AS_LDS double*)gb(g, k) = v; }
   MSB_HD MSB_INL static double wtab(int age) { return lds_wtab(age); }
+  MSB_HD MSB_INL static void trace_ability(int, int) {}
+};
+// The same with the ability log of the scenario tests switched on: {card, position} pairs appended to an LDS array
+// (count at TRACE_BASE, pairs behind it).  Only the one-lane diagnostics kernel of monsoon_debug_op uses it.
+template <int LANES, int BASE, int TRACE_BASE, int TRACE_CAP>
+struct TraceLaneMem : LaneMem<LANES, BASE> {
+  MSB_HD MSB_INL static void trace_ability(int card, int pos) {
+    MSB_AS_LDS int32_t* t = (MSB_AS_LDS int32_t*)(uintptr_t)TRACE_BASE;
+    int n = t[0];
+    if (n < TRACE_CAP) {
+      t[1 + 2 * n] = card;
+      t[2 + 2 * n] = pos;
+      t[0] = n + 1;
+    }
+  }
 };
 template <int BASE>
 struct SharedMem {   // one contiguous record read by every lane of the wave (LDS broadcast)
@@ -291,6 +323,7 @@ struct SharedMem {   // one contiguous record read by every lane of the wave (LD
   MSB_HD MSB_INL static double ldfg(int g, int k) { return ldf(g * 16 + k); }
   MSB_HD MSB_INL static void stfg(int g, int k, double v) { stf(g * 16 + k, v); }
   MSB_HD MSB_INL static double wtab(int age) { return lds_wtab(age); }
+  MSB_HD MSB_INL static void trace_ability(int, int) {}
 };
 #endif
 

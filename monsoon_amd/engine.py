@@ -144,6 +144,24 @@ class BatchEngine:
         if i == self.n:
             self.n = i + 1
 
+    def debug_build(self, i, seed, stream_pos, state):
+        """Scenario tests: put game i into a described state (int32 stream, tests/scenario_lib.py); returns the fault code."""
+        state = np.ascontiguousarray(state, dtype=np.int32)
+        f = ctypes.c_int32()
+        self._ck(self.lib.monsoon_debug_build(self.h, i, int(seed) & 0xFFFFFFFF, int(stream_pos), _ptr(state), len(state), ctypes.byref(f)),
+                 "monsoon_debug_build")
+        if i == self.n:
+            self.n = i + 1
+        return f.value
+
+    def debug_op(self, i, op):
+        """One engine call on game i; returns (fault code, [[card, position], ...] of the abilities that ran, in order)."""
+        op = np.ascontiguousarray(op, dtype=np.int32)
+        log = np.zeros(512, dtype=np.int32)
+        f, n = ctypes.c_int32(), ctypes.c_int32()
+        self._ck(self.lib.monsoon_debug_op(self.h, i, _ptr(op), len(op), ctypes.byref(f), _ptr(log), 256, ctypes.byref(n)), "monsoon_debug_op")
+        return f.value, log[:2 * n.value].reshape(-1, 2).tolist()
+
     def debug_raw(self, i):
         buf = np.zeros(4096, dtype=np.uint8)
         ln = ctypes.c_int32()

@@ -325,6 +325,42 @@ uint64_t orc_rollout_batch(void* h, int n, const double* w, int max_turns, int n
   return total.load();
 }
 
+// ---- scenario tests (tests/scenario_lib.py): the reference's own unit tests, recorded call by call ---------------
+// Build game gi from a state stream, its numpy stream being RandomState(seed) advanced by stream_pos outputs.
+int orc_scn_build(void* h, int gi, uint32_t seed, uint32_t stream_pos, const int32_t* state) {
+  Game& g = ((Oracle*)h)->games[gi];
+  seed_game(g, seed);
+  g.result = -2;
+  g.steps = 0;
+  g.lookahead_steps = 0;
+  memset(g.st, 0, sizeof(g.st));
+  uint32_t blocks = stream_pos / MT_N;
+  for (uint32_t b = 0; b < blocks; b++) {
+    int old = g.cur;
+    g.cur ^= 1;
+    refill(g, old);
+  }
+  g.pos = stream_pos % MT_N;
+  Engine<FlatMem> e = engine(g);
+  if (REM_LISTS) e.m.st16(X_RNGBLK, (int)blocks);
+  e.scn_build(state, seed);
+  return e.fault();
+}
+// One recorded call.  log: {card, position} of every ability that ran, in order; returns the fault code.
+int orc_scn_op(void* h, int gi, const int32_t* op, int32_t* log, int log_cap, int* n_log) {
+  Game& g = ((Oracle*)h)->games[gi];
+  Engine<FlatMem> e = engine(g);
+  msb_trace_log = log;
+  msb_trace_n = 0;
+  msb_trace_cap = log ? log_cap : 0;
+  int f = e.scn_op(op);
+  if (n_log) *n_log = msb_trace_n;
+  msb_trace_log = nullptr;
+  msb_trace_cap = 0;
+  commit_rng(g, e);
+  return f;
+}
+
 // ---- RNG known-answer entry points (tests/golden/rng_kat.npz) ---------------------------------
 void orc_rng_u32(uint32_t seed, int n, uint32_t* out) {
   Game g;

@@ -11,6 +11,7 @@ by running it here and committing inputs + expected outputs (data only, no refer
                                observation hash, reward, done (+ features for N12M)
   trace_pool.npz           G3/G5 random 12-card decks from the 107 cards of the standard record (card coverage)
   trace_pool_ext.npz       G3/G5 the same over all 109 observable cards (ua20, b005: extended record)
+  trace_pool_up.npz        G6 decks holding up01 / up02 / up03, whose int(card) makes get_observation raise
   trace_expert.npz         (f1) both sides driven by Stormbound.expert_action (the bot's choices are the actions)
   trace_heuristic_N12M.npz G3  corrected heuristic self-play (SURVEY §8c contract), W0 both sides:
                                chosen action, best score, score hash, state hash per decision
@@ -215,6 +216,30 @@ def gen_pool(n_games, steps, jobs, ext=False):
     pack_traces("trace_pool_ext.npz" if ext else "trace_pool.npz", jobs, results, decks0, decks1)
 
 
+def gen_pool_up(n_games, steps, jobs):
+    """G6: decks holding up01 / up02 / up03, whose int(card) raises (card.py:46): get_observation -- and with it
+    Stormbound.step -- raises as soon as one of them is visible to the mover (own hand / deck, board, last-4 history).
+    A third of the games hold one in the FIRST player's deck (the very first step raises), the rest only in the second
+    player's (the first PASS, or the card appearing in the history / on the board, raises)."""
+    pool = [c for c in H.CARD_IDS if c not in UNSUPPORTED and c not in FAULT_CARDS]
+    ups = sorted(FAULT_CARDS)
+    tasks, decks0, decks1 = [], [], []
+    for k in range(n_games):
+        seed = 42000 + k
+        rs = np.random.RandomState(seed ^ 0x9E3779B9)
+        d0 = list(rs.choice(pool, 12, replace=False))
+        d1 = list(rs.choice(pool, 12, replace=False))
+        (d0 if k % 3 == 0 else d1)[int(rs.randint(0, 12))] = ups[k % 3]
+        if k % 5 == 4:
+            d1[0], d1[1], d1[2] = ups   # all three at once
+        tasks.append((seed, d0, d1, steps, False))
+        decks0.append(idx(d0))
+        decks1.append(idx(d1))
+    with ProcessPoolExecutor(jobs) as ex:
+        results = list(ex.map(random_trace, tasks))
+    pack_traces("trace_pool_up.npz", jobs, results, decks0, decks1)
+
+
 # ---------------------------------------------------------------------------------------------
 def heuristic_trace(args):
     """Corrected rollout loop: while not have_winner() and steps < max_turns."""
@@ -405,6 +430,7 @@ def main():
         "random_IRONCLAD": lambda: gen_random("IRONCLAD", "SWARM", 32, 300, args.jobs),
         "pool": lambda: gen_pool(160, 300, args.jobs),
         "pool_ext": lambda: gen_pool(120, 300, args.jobs, ext=True),   # all 109 observable cards (ua20, b005 included)
+        "pool_up": lambda: gen_pool_up(30, 300, args.jobs),   # up01/up02/up03: int(card) raises (G6)
         "random_S12": lambda: gen_random("S12", None, 48, 300, args.jobs),
         "expert": lambda: gen_expert(48, 300, args.jobs),
         "heuristic": lambda: gen_heuristic(12, 200, args.jobs),

@@ -29,4 +29,18 @@ for ext in (False, True):
     d=deck_indices("N12M").copy(); d[0]=CARD_INDEX["up01"]
     orc.reset(0,1,d,d); orc.rollout(0,W0,W0,50)
     print("ext" if ext else "std", "look-ahead steps under ASan/UBSan:", n, flush=True)
-print("sanitizers clean")
+print("sanitizers clean (rollouts)")
+# the scenario fixtures (the reference's own tests, call by call): state builder + single engine calls, both builds
+import scenario_lib as S
+ext_cards = [CARD_INDEX["ua20"], CARD_INDEX["b005"]]
+orcs = {False: oracle_lib.Oracle(1), True: oracle_lib.Oracle(1, extended=True)}
+n = 0
+for case in S.load():
+    for rec in case["records"]:
+        for ext in sorted({S.needs_extended(rec, ext_cards), True}):   # everything also on the extended build
+            st = rec["before"]
+            orcs[ext].scn_build(0, st["seed"], st["stream_pos"], S.encode_state(st))
+            orcs[ext].scn_op(0, S.encode_op(rec))
+            n += 1
+print("scenario calls under ASan/UBSan:", n)
+print("sanitizers clean (scenarios)")

@@ -147,6 +147,19 @@ class Oracle:
         a = self.L.orc_decide(self.h, i, _p(w), _p(scores), _p(mask))
         return a, scores, mask
 
+    def scn_build(self, i, seed, stream_pos, state):
+        """Scenario tests: game i from a state stream (tests/scenario_lib.py), stream = RandomState(seed) + stream_pos."""
+        state = np.ascontiguousarray(state, dtype=np.int32)
+        return self.L.orc_scn_build(self.h, i, ctypes.c_uint32(int(seed)), ctypes.c_uint32(int(stream_pos)), _p(state))
+
+    def scn_op(self, i, op):
+        """One recorded engine call; returns (fault code, [[card, position tile or -1], ...] of the abilities that ran)."""
+        op = np.ascontiguousarray(op, dtype=np.int32)
+        log = np.zeros(2 * 256, dtype=np.int32)
+        n = ctypes.c_int()
+        f = self.L.orc_scn_op(self.h, i, _p(op), _p(log), 256, ctypes.byref(n))
+        return f, log[:2 * n.value].reshape(-1, 2).tolist()
+
     def lookahead_faults(self, i):
         """Fault code of each legal action's look-ahead (255 = not legal); 20 = flagged as unsupported by this build."""
         out = np.zeros(156, dtype=np.uint8)

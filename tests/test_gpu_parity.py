@@ -40,7 +40,7 @@ def test_initial_states_vs_reference(engines, gold):
 
 
 @pytest.mark.parametrize("name", ["trace_random_N12V.npz", "trace_random_N12M.npz", "trace_random_IRONCLAD.npz",
-                                  "trace_random_S12.npz", "trace_pool.npz", "trace_pool_ext.npz"])
+                                  "trace_random_S12.npz", "trace_pool.npz", "trace_pool_ext.npz", "trace_pool_up.npz"])
 def test_random_policy_traces_vs_reference(engines, gold, name):
     """Replays the reference's seeded random-policy games through monsoon_step in lockstep
     (trace_pool_ext: all 109 observable cards on the extended-record build)."""
@@ -235,6 +235,36 @@ def test_small_batches_play_every_game(engines):
         assert (r["result"], r["steps"]) == (results[i], steps[i]), i
     assert counts[0, 2] == cap + 1
     eng.close()
+
+
+def test_reference_unit_tests_as_scenarios_on_gpu():
+    """The reference's own 113 unit tests (112 card tests + the engine-level trigger-order / respawn test, test.py:53-147),
+    recorded call by call on the reference (tests/golden/scenarios.json.gz): the HIP engine is put into the state the
+    reference had (monsoon_debug_build), makes the one call (monsoon_debug_op) and must land on the REFERENCE's canonical
+    state and on the reference's order of ability activations -- fixture vs HIP, no oracle in between."""
+    import scenario_lib as S
+    from monsoon_amd.cards import CARD_INDEX
+    from monsoon_amd.engine import BatchEngine
+    ext_cards = [CARD_INDEX["ua20"], CARD_INDEX["b005"]]
+    engs = {False: BatchEngine(2), True: BatchEngine(2, extended=True)}
+    n_calls, n_tests = 0, 0
+    for case in S.load():
+        for k, rec in enumerate(case["records"]):
+            eng = engs[S.needs_extended(rec, ext_cards)]
+            st = rec["before"]
+            assert eng.debug_build(0, st["seed"], st["stream_pos"], S.encode_state(st)) == 0, (case["test"], k)
+            f, log = eng.debug_op(0, S.encode_op(rec))
+            if rec["raised"]:
+                assert f != 0, (case["test"], k, rec["op"])
+                continue
+            assert f == 0, (case["test"], k, rec["op"], f)
+            assert eng.export(0).hex() == rec["after"], (case["test"], k, rec["op"])
+            assert log == S.expected_log(rec), (case["test"], k, rec["op"])
+            n_calls += 1
+        n_tests += 1
+    assert n_tests == 113 + 7 and n_calls > 550   # + the quirk scenarios of SURVEY §0 (G6)
+    for e in engs.values():
+        e.close()
 
 
 def test_play_rounds_equals_single_decision_rounds():

@@ -73,7 +73,8 @@ def _replay(orc, g, k, check_feat=False):
 
 @pytest.mark.parametrize("name,feat", [("trace_random_N12V.npz", False), ("trace_random_N12M.npz", True),
                                        ("trace_random_IRONCLAD.npz", False), ("trace_random_S12.npz", False),
-                                       ("trace_pool.npz", False)])
+                                       ("trace_pool.npz", False),
+                                       ("trace_pool_up.npz", False)])
 def test_random_policy_traces(oracle_mod, gold, name, feat):
     g = gold(name)
     orc = oracle_mod.Oracle(1)
@@ -218,3 +219,33 @@ def test_quirk_spell_lands_one_tile_late(oracle_mod):
             if orc.have_winner(0):
                 break
     assert seen > 0
+
+
+def test_reference_unit_tests_as_scenarios(oracle_mod):
+    """The reference's OWN tests: 112 `class <ID>Test(CardTestCase)` next to the cards and the
+    engine-level BaseTestCase (test.py:53-147: LIFO order of a 16-unit U401 chain reaction, trigger order vs move order,
+    respawn), recorded call by call on the reference (oracle/pyref/gen_scenarios.py; all 113 pass there).  For every
+    recorded call: load the state the reference had, make the call, land on the reference's canonical state and on the
+    reference's order of ability activations."""
+    import scenario_lib as S
+    from monsoon_amd.cards import CARD_INDEX
+    ext_cards = [CARD_INDEX["ua20"], CARD_INDEX["b005"]]
+    orcs = {False: oracle_mod.Oracle(1), True: oracle_mod.Oracle(1, extended=True)}
+    n_calls, n_tests, orders = 0, 0, 0
+    for case in S.load():
+        for k, rec in enumerate(case["records"]):
+            ext = S.needs_extended(rec, ext_cards)
+            orc = orcs[ext]
+            st = rec["before"]
+            assert orc.scn_build(0, st["seed"], st["stream_pos"], S.encode_state(st)) == 0, (case["test"], k)
+            f, log = orc.scn_op(0, S.encode_op(rec))
+            if rec["raised"]:
+                assert f != 0, (case["test"], k, rec["op"])
+                continue
+            assert f == 0, (case["test"], k, rec["op"], f)
+            assert orc.canon(0).hex() == rec["after"], (case["test"], k, rec["op"])
+            assert log == S.expected_log(rec), (case["test"], k, rec["op"])
+            orders += len(log)
+            n_calls += 1
+        n_tests += 1
+    assert n_tests == 113 + 7 and n_calls > 550 and orders > 150   # + the quirk scenarios of SURVEY §0 (G6)
