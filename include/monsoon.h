@@ -129,6 +129,13 @@ int monsoon_state_load(monsoon_t* h, int32_t idx, const uint8_t* buf, int32_t bu
 int monsoon_debug_build(monsoon_t* h, int32_t idx, uint32_t seed, uint32_t stream_pos, const int32_t* state, int32_t n_state, int32_t* fault);
 int monsoon_debug_op(monsoon_t* h, int32_t idx, const int32_t* op, int32_t n_op, int32_t* fault, int32_t* log, int32_t log_cap, int32_t* n_log);
 
+/* Diagnostics: the device's numpy-stream draws and score arithmetic on caller-given inputs (numpy.random.RandomState
+ * legacy API: player.py:28,49, unit.py:95, cards; np.dot of evo/weights.py:60), for known-answer tests.  kind 0: n raw
+ * u32 outputs of RandomState(seed); 1: n random(); 2: randint(0, in[i]) for n int32 bounds; 3: n times
+ * shuffle(list(range(12))) (out int32[n][12]); 4: n scores of in = double[n][30] {weights, before, after}.  n <= 4096.
+ * Re-seeds the stream buffers of game slot 0. */
+int monsoon_debug_kat(monsoon_t* h, int32_t kind, uint32_t seed, int32_t n, const void* in, void* out);
+
 /* Debugging aid: the raw HBM record of game idx (monsoon_amd/csrc/state.h layout); buf must hold 4096 bytes. */
 int monsoon_debug_raw(monsoon_t* h, int32_t idx, uint8_t* buf, int32_t* len);
 

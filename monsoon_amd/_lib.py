@@ -63,6 +63,7 @@ SIGNATURES = {
                                            ctypes.POINTER(ctypes.c_int32)]),
     "monsoon_debug_op": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p, ctypes.c_int32, ctypes.POINTER(ctypes.c_int32),
                                         ctypes.c_void_p, ctypes.c_int32, ctypes.POINTER(ctypes.c_int32)]),
+    "monsoon_debug_kat": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32, ctypes.c_uint32, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p]),
     "monsoon_debug_raw": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p, ctypes.POINTER(ctypes.c_int32)]),
     "monsoon_state_hash": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p]),
     "monsoon_decide": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),

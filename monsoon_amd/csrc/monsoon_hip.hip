@@ -327,6 +327,50 @@ __global__ void __launch_bounds__(64) k_debug(DevBuffers b, int g, int build, ui
   for (int i = 0; i < 2 * n; i++) out[2 + i] = tr[1 + i];
 }
 
+// monsoon_debug_kat (diagnostics): the device's numpy-stream draws and its score arithmetic on caller-given inputs, so
+// that the known-answer vectors generated from numpy itself (tests/golden/rng_kat.npz, score_kat.npz) can be put to the
+// HIP code directly.  One lane; the draws come from game 0's stream buffers, freshly seeded by the host side.
+__global__ void __launch_bounds__(64) k_kat(DevBuffers b, int kind, int n, const void* in, void* out) {
+  lds_init_wtab();
+  if (threadIdx.x != 0) return;
+  DbgEngine e;
+  MSB_AS_LDS u32x4* rec = (MSB_AS_LDS u32x4*)(uintptr_t)LDS_ORIGIN;
+  for (int c = 0; c < SG; c++) rec[c] = u32x4{0u, 0u, 0u, 0u};
+  GameMeta m = GameMeta{};
+  attach_rng(e, b, 0, m.rng);
+  auto commit = [&]() {   // keep the window ahead of the cursor, as every committed step does
+    if (e.rng_pos() >= (uint32_t)MT_N) {
+      lane_commit_rng(b, 0, m, e.rng_pos());
+      attach_rng(e, b, 0, m.rng);
+    }
+  };
+  for (int i = 0; i < n; i++) {
+    if (kind == 0) ((uint32_t*)out)[i] = e.rng_next_u32();
+    else if (kind == 1) ((double*)out)[i] = e.rng_random_sample();
+    else if (kind == 2) ((int32_t*)out)[i] = e.rng_randint(0, ((const int32_t*)in)[i]);
+    else if (kind == 3) {   // shuffle(list(range(12)))
+      int32_t* a = (int32_t*)out + 12 * i;
+      for (int k = 0; k < 12; k++) a[k] = k;
+      for (int k = 11; k >= 1; k--) {
+        int j = (int)e.rng_interval((uint32_t)k);
+        int t = a[k];
+        a[k] = a[j];
+        a[j] = t;
+      }
+    } else {                // score of (w[10], before[10], after[10])
+      const double* r = (const double*)in + 30 * i;
+      double w[10], fb[10], fa[10];
+      for (int k = 0; k < 10; k++) {
+        w[k] = r[k];
+        fb[k] = r[10 + k];
+        fa[k] = r[20 + k];
+      }
+      ((double*)out)[i] = DbgEngine::action_score(w, fb, fa);
+    }
+    commit();
+  }
+}
+
 // monsoon_state_save / monsoon_state_load: one game's complete device state as a flat blob
 // {u32 magic, u32 record bytes, GameMeta, record, raw MT state, two tempered blocks}
 constexpr uint32_t BLOB_MAGIC = 0x4d53424cu ^ (uint32_t)STATE_BYTES;
@@ -850,6 +894,44 @@ int monsoon_debug_op(monsoon_t* h, int32_t idx, const int32_t* op, int32_t n_op,
     return MONSOON_ERR_ARG;
   }
   return debug_call(h, idx, 0, 0, 0, op, n_op, fault, log, log_cap, n_log);
+}
+
+// kind 0: n raw u32 draws of RandomState(seed); 1: n random() doubles; 2: randint(0, in[i]) for n int32 bounds; 3: n x
+// shuffle(list(range(12))) on one stream (out int32[n][12]); 4: n scores of in = double[n][30] {weights, before, after}.
+// Uses (and re-seeds) the stream buffers of game slot 0.
+int monsoon_debug_kat(monsoon_t* h, int32_t kind, uint32_t seed, int32_t n, const void* in, void* out) {
+  if (!h || !out || n <= 0 || n > 4096 || kind < 0 || kind > 4 || ((kind == 2 || kind == 4) && !in)) {
+    if (h) h->err = "monsoon_debug_kat: bad argument";
+    return MONSOON_ERR_ARG;
+  }
+  HIP_TRY(h, hipSetDevice(h->device));
+  const size_t in_bytes = kind == 2 ? (size_t)n * 4 : (kind == 4 ? (size_t)n * 240 : 0);
+  const size_t out_bytes = kind == 3 ? (size_t)n * 48 : (kind == 1 || kind == 4 ? (size_t)n * 8 : (size_t)n * 4);
+  void *d_in = nullptr, *d_out = nullptr;
+  HIP_TRY(h, hipMalloc(&d_out, out_bytes));
+  if (in_bytes) {
+    hipError_t e = hipMalloc(&d_in, in_bytes);
+    if (e == hipSuccess) e = hipMemcpy(d_in, in, in_bytes, hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+      hipFree(d_out);
+      if (d_in) hipFree(d_in);
+      h->err = std::string("monsoon_debug_kat: ") + hipGetErrorString(e);
+      return MONSOON_ERR_DEVICE;
+    }
+  }
+  hipMemcpyAsync(h->d_seeds, &seed, 4, hipMemcpyHostToDevice, h->stream);
+  hipLaunchKernelGGL(k_seed, dim3(1), dim3(64), 0, h->stream, h->b, 0, 1, h->d_seeds);
+  hipLaunchKernelGGL(k_kat, dim3(1), dim3(64), DBG_LDS_BYTES, h->stream, h->b, kind, n, (const void*)d_in, d_out);
+  hipError_t e = hipGetLastError();
+  if (e == hipSuccess) e = hipMemcpyAsync(out, d_out, out_bytes, hipMemcpyDeviceToHost, h->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+  hipFree(d_out);
+  if (d_in) hipFree(d_in);
+  if (e != hipSuccess) {
+    h->err = std::string("monsoon_debug_kat: ") + hipGetErrorString(e);
+    return MONSOON_ERR_DEVICE;
+  }
+  return MONSOON_OK;
 }
 
 int monsoon_game_faults(monsoon_t* h, uint8_t* out) {

@@ -162,6 +162,15 @@ class BatchEngine:
         self._ck(self.lib.monsoon_debug_op(self.h, i, _ptr(op), len(op), ctypes.byref(f), _ptr(log), 256, ctypes.byref(n)), "monsoon_debug_op")
         return f.value, log[:2 * n.value].reshape(-1, 2).tolist()
 
+    def debug_kat(self, kind, seed, n, inp=None):
+        """Known-answer diagnostics (monsoon_debug_kat): 0 raw u32, 1 random(), 2 randint(0, inp[i]), 3 shuffle of range(12),
+        4 scores of inp[n][30] = {weights, before, after}."""
+        out = np.zeros((n, 12) if kind == 3 else n, dtype={0: np.uint32, 1: np.float64, 2: np.int32, 3: np.int32, 4: np.float64}[kind])
+        if inp is not None:
+            inp = np.ascontiguousarray(inp, dtype=np.int32 if kind == 2 else np.float64)
+        self._ck(self.lib.monsoon_debug_kat(self.h, kind, int(seed) & 0xFFFFFFFF, n, _ptr(inp), _ptr(out)), "monsoon_debug_kat")
+        return out
+
     def debug_raw(self, i):
         buf = np.zeros(4096, dtype=np.uint8)
         ln = ctypes.c_int32()

@@ -24,3 +24,16 @@ def oracle_rollout_fn(weights, matches, deck_pairs, max_turns, want_results=Fals
             counts[int(m["p1"]), 1] += 1
         counts[int(m["p1"]), 2] += 1
     return (counts, results, steps) if want_results else counts
+
+
+def oracle_rollout_fn_mt(weights, matches, deck_pairs, max_turns, want_results=False, threads=16):
+    """The same on several host threads (ctypes releases the GIL): for the larger GPU-vs-CPU comparisons."""
+    from concurrent.futures import ThreadPoolExecutor
+    matches = np.asarray(matches)
+    chunks = [c for c in np.array_split(np.arange(len(matches)), threads) if len(c)]
+    with ThreadPoolExecutor(len(chunks)) as ex:
+        parts = list(ex.map(lambda idx: oracle_rollout_fn(weights, matches[idx], deck_pairs, max_turns, want_results=True), chunks))
+    counts = sum(p[0] for p in parts)
+    results = np.concatenate([p[1] for p in parts])
+    steps = np.concatenate([p[2] for p in parts])
+    return (counts, results, steps) if want_results else counts

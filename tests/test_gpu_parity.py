@@ -55,6 +55,8 @@ def test_random_policy_traces_vs_reference(engines, gold, name):
         orc.reset(k, int(g["seeds"][k]), g["deck0"][k], g["deck1"][k])
     off = g["offsets"]
     lens = (off[1:] - off[:-1]).copy()
+    # feature rows exist for the steps the reference completed: a game whose last step raised has one row less
+    foff = np.concatenate([[0], np.cumsum(lens - g["fault"].astype(np.int64))]) if "feat" in g.files else None
     for t in range(int(lens.max())):
         live = np.nonzero(lens > t)[0]
         masks = eng.legal_mask()
@@ -65,6 +67,7 @@ def test_random_policy_traces_vs_reference(engines, gold, name):
         reward, done, fault = eng.step(acts)
         hashes = eng.state_hash()
         obs, raises = eng.observe()
+        feat = eng.features() if "feat" in g.files else None
         for k in live:
             i = off[k] + t
             fo, _, _ = orc.step(k, int(acts[k]))
@@ -75,11 +78,8 @@ def test_random_policy_traces_vs_reference(engines, gold, name):
             assert hashes[k] == g["hash"][i], (k, t)
             assert (reward[k], done[k]) == (g["reward"][i], g["done"][i]), (k, t)
             assert np.array_equal(obs[k], orc.observe(k)), (k, t)
-    if "feat" in g.files:
-        feat = eng.features()
-        for k in range(n):
-            if not g["fault"][k]:
-                assert np.array_equal(feat[k].view(np.uint64), g["feat"][off[k + 1] - 1].view(np.uint64)), k
+            if feat is not None:   # the reference's StateFeatures at EVERY step (the fixture holds no rows for faulted steps)
+                assert np.array_equal(feat[k].view(np.uint64), g["feat"][foff[k] + t].view(np.uint64)), (k, t)
 
 
 def test_expert_bot_vs_reference(engines, gold):
@@ -234,6 +234,26 @@ def test_small_batches_play_every_game(engines):
         r = orc.rollout(0, W0, W0, 60)
         assert (r["result"], r["steps"]) == (results[i], steps[i]), i
     assert counts[0, 2] == cap + 1
+    eng.close()
+
+
+def test_numpy_stream_and_dot_known_answers_on_gpu(gold):
+    """numpy's own outputs (tests/golden/rng_kat.npz: raw MT19937 words, random(), randint, shuffle; score_kat.npz: 2 000
+    scores through np.dot) against the HIP code that restates them -- fixture vs device, bit for bit."""
+    from monsoon_amd.engine import BatchEngine
+    eng = BatchEngine(2)
+    r = gold("rng_kat.npz")
+    b = np.ascontiguousarray(r["randint_bounds"])
+    for s in r["seeds"]:
+        s = int(s)
+        assert np.array_equal(eng.debug_kat(0, s, 1500), r[f"u32_{s}"]), s          # crosses two block refills
+        assert np.array_equal(eng.debug_kat(1, s, 400).view(np.uint64), r[f"random_{s}"].view(np.uint64)), s
+        assert np.array_equal(eng.debug_kat(2, s, len(b), b), r[f"randint_{s}"]), s
+        assert np.array_equal(eng.debug_kat(3, s, 20), r[f"shuffle12_{s}"]), s
+    k = gold("score_kat.npz")
+    rows = np.concatenate([k["w"], k["before"], k["after"]], axis=1)
+    got = eng.debug_kat(4, 0, len(rows), rows)
+    assert np.array_equal(got.view(np.uint64), k["score"].view(np.uint64))
     eng.close()
 
 
@@ -435,6 +455,77 @@ def test_random_deck_rollouts_extended_build_bit_exact(engines):
     # state.h) -- what remains are the capacity limits of the record (entity slots, memory lists, worlds, deck
     # entries), reported per game and required to stay below 0.5 % here
     assert (faults == 1).sum() > n // 10 and (faults == 20).sum() == 0 and (faults >= 16).sum() <= n // 200
+
+
+def test_config_c3_ga_loop_through_the_hip_path(tmp_path):
+    """BASELINE configs[2] (C3): the GA driver loop of evo/evolution.py:60-111 -- mu = lambda = 128, 64 games per
+    individual (ring schedule), N12M, seed 42 -- for two generations (8 192 + 16 384 games, 200 decisions each) through
+    EvolutionEngine -> FitnessEvaluator -> monsoon_rollout.  The same run on the CPU replay gives the same fitness list,
+    the same selected population and the same best individual."""
+    from oracle_rollout import oracle_rollout_fn_mt
+    from monsoon_amd.config import EvolutionaryConfig
+    from monsoon_amd.evolution import EvolutionEngine
+    runs = []
+    for name, fn in (("hip", None), ("cpu", oracle_rollout_fn_mt)):
+        cfg = EvolutionaryConfig(mu=128, lambda_=128, generations=2, schedule="ring", games_per_individual=64, deck="N12M", max_turns=200,
+                                 seed=42, results_dir=str(tmp_path / name), save_logs=False, checkpoint_interval=1000,
+                                 max_concurrent_games=16384)
+        eng = EvolutionEngine(cfg, rollout_fn=fn)
+        eng.initialize()
+        res = eng.run()
+        runs.append((list(eng.population.fitness_scores), np.stack([i.get_weights() for i in eng.population.individuals]), res))
+        if fn is None:
+            st = eng.fitness_evaluator.get_stats()
+            assert st["total_games"] == 128 * 64 + 256 * 64 and st["env_steps"] > 50_000_000
+    (f_hip, w_hip, r_hip), (f_cpu, w_cpu, r_cpu) = runs
+    assert f_hip == f_cpu
+    assert np.array_equal(w_hip.view(np.uint64), w_cpu.view(np.uint64))
+    assert r_hip["best_fitness"] == r_cpu["best_fitness"] and r_hip["generations"] == 2
+
+
+def test_config_c4_shape_on_one_gpu():
+    """BASELINE configs[3] (C4) on one GPU: population 1 024 on the Swarm deck S12 (on-death / summon triggers), ring
+    schedule, 8 games per individual = 8 192 games through FitnessEvaluator; per-individual fitness equals the CPU replay
+    of the same schedule.  (The 8-GPU form shards this schedule by row individual: tests/test_distributed_cpu.py.)"""
+    from oracle_rollout import oracle_rollout_fn_mt
+    from monsoon_amd.config import EvolutionaryConfig
+    from monsoon_amd.fitness import FitnessEvaluator
+    from monsoon_amd.weights import WeightVector
+    np.random.seed(5)
+    pop = [WeightVector(10) for _ in range(1024)]
+    cfg = EvolutionaryConfig(mu=1024, lambda_=1024, schedule="ring", games_per_individual=8, deck="S12", max_turns=200,
+                             max_concurrent_games=8192)
+    f_hip = FitnessEvaluator(cfg).evaluate_population(pop, generation=7)
+    f_cpu = FitnessEvaluator(cfg, rollout_fn=oracle_rollout_fn_mt).evaluate_population(pop, generation=7)
+    assert f_hip == f_cpu
+    assert len(set(f_hip)) > 5   # games do get decided on this deck
+
+
+def test_failed_rollouts_leave_device_memory_alone():
+    """A schedule whose bad entry sits in what would be the SECOND batch is refused before anything is loaded, and
+    repeated refusals (and successes) do not move the device's free memory: the rollout's result buffers live in the
+    handle, nothing is allocated or leaked per call."""
+    import torch
+    from monsoon_amd import MonsoonError
+    from monsoon_amd.engine import BatchEngine
+    deck = deck_indices("N12M")
+    pairs = np.stack([deck, deck])[None]
+    dt = [("p1", "<i4"), ("p2", "<i4"), ("seed", "<u4"), ("deck", "<u4")]
+    eng = BatchEngine(32)
+    good = np.zeros(40, dtype=dt)
+    eng.rollout(W0[None], good, pairs, 5)          # allocates the handle's buffers once
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info()[0]
+    bad = np.zeros(40, dtype=dt)
+    bad["p2"][36] = 9                              # second batch (capacity 32): only individual 0 exists
+    for _ in range(5):
+        with pytest.raises(MonsoonError, match="schedule entry 36"):
+            eng.rollout(W0[None], bad, pairs, 5)
+        counts = eng.rollout(W0[None], good, pairs, 5)
+        assert counts[0, 2] == 40
+    torch.cuda.synchronize()
+    assert torch.cuda.mem_get_info()[0] == free0
+    eng.close()
 
 
 def test_observation_tensor_view_on_device(engines):
