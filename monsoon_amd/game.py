@@ -90,6 +90,22 @@ class Stormbound:
     def state_record(self):
         return self._eng.export(0)
 
+    def clone(self):
+        """copy.deepcopy(game) (evo/game_adapter.py:280-287 clone_state): a second device-resident game holding the complete
+        state -- stream position included, so the clone continues exactly like the original would."""
+        other = Stormbound.__new__(Stormbound)
+        other.seed, other._decks, other._factions = self.seed, self._decks, self._factions
+        other._eng = BatchEngine(1, device=self._eng.device, extended=self._eng.extended)
+        other._eng.load_state(0, self._eng.save_state(0))
+        return other
+
+    def features(self):
+        """StateFeatures(observation, to_play).get_feature_vector() (evo/features.py:327-342) of the current state."""
+        return self._eng.features()[0]
+
+    def close(self):
+        self._eng.close()
+
     def render(self):
         obs = self.get_observation()
         rows = []
@@ -131,7 +147,13 @@ class Game:
         self.env.render()
 
     def close(self):
-        self.env._eng.close()
+        self.env.close()
+
+    def clone(self):
+        """StormboundAdapter.clone_state (evo/game_adapter.py:280-287): an independent copy of the whole game."""
+        other = Game.__new__(Game)
+        other.env = self.env.clone()
+        return other
 
     def expert_agent(self):
         return self.env.expert_action()             # games/stormbound.py:227-235

@@ -311,6 +311,43 @@ def test_play_rounds_equals_single_decision_rounds():
     bq.close()
 
 
+def test_python_level_lookahead_on_clones_equals_the_fused_decision():
+    """Seam G alone is enough to run the reference's agent layer: HeuristicAgent.score_action (evo/heuristic_agent.py:23-51)
+    written in Python over Game.clone() + step() + features() -- deepcopy, apply, feature delta, np.dot -- gives, for every
+    legal action of every decision of a game, exactly the score vector of the fused monsoon_decide, and its first maximum
+    is the action monsoon_decide commits."""
+    from monsoon_amd.engine import BatchEngine
+    from monsoon_amd.game import Game, StepFault
+    deck = "N12M"
+    g = Game(21, deck0=deck, deck1=deck, faction0=0, faction1=0)
+    fused = BatchEngine(1)
+    fused.reset(np.array([21], dtype=np.uint32), np.stack([deck_indices(deck), deck_indices(deck)]))
+    for t in range(30):
+        legal = g.legal_actions()
+        before = g.env.features()
+        scores = []
+        for a in legal:
+            c = g.clone()
+            try:
+                c.step(a)
+                d = c.env.features() - before                     # _compute_feature_delta
+                agent, enemy = np.dot(W0, d), np.dot(W0, -d)       # WeightVector.dot_product
+                eff = d[0]
+                pen = abs(eff) * 0.2 if eff < -0.3 else 0.0        # _compute_resource_delta
+                scores.append(enemy - agent - pen)
+            except (StepFault, ValueError):
+                scores.append(0.0)                                 # except Exception: return 0.0
+            c.close()
+        action, best, full = fused.decide(W0, want_scores=True)
+        assert [a for a in range(156) if not np.isnan(full[0, a])] == legal, t
+        assert np.array_equal(np.array(scores).view(np.uint64), full[0, legal].view(np.uint64)), t
+        assert legal[int(np.argmax(scores))] == action[0], t
+        g.step(int(action[0]))
+        assert g.env.state_record() == fused.export(0), t
+    g.close()
+    fused.close()
+
+
 def test_state_save_load_round_trip_and_clone(engines):
     """monsoon_state_save / monsoon_state_load: export -> import -> export is byte-identical for every state of a game,
     and a clone loaded into another handle continues exactly like the original (copy.deepcopy incl. the stream)."""
