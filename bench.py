@@ -19,7 +19,7 @@ committed successor is one of them and is not re-executed) divided by the wall t
 ranks / max over ranks.  Inputs are resident in HBM when the timed region starts (c2; c4 uploads 80 KB of weights
 and a 1 MB schedule per generation, as the GA driver does).
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2|c4] [--games G] [--lanes U] [--rounds R] [--no-cpu]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2|c4|rollout] [--deck D] [--games G] [--lanes U] [--rounds R] [--no-cpu]
 With --gpus N > 1 and no WORLD_SIZE in the environment this process starts the N ranks itself (one process per
 GPU through torch.distributed.run, before anything here touches a GPU) and relays rank 0's line; under
 torch.distributed.run it is one of the ranks.
@@ -119,19 +119,20 @@ def parse_args(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=None)
     ap.add_argument("--warmup", type=int, default=None)
-    ap.add_argument("--workload", choices=["c2", "c4"], default="c2")
+    ap.add_argument("--workload", choices=["c2", "c4", "rollout"], default="c2")
+    ap.add_argument("--deck", default="N12M", help="rollout workload: a named deck (both sides), or 'random' = C5's per-game 12-card decks")
     ap.add_argument("--games", type=int, default=65536)
     ap.add_argument("--lanes", type=int, default=0, help="candidate lanes per game (0 = build default)")
     ap.add_argument("--rounds", type=int, default=8, help="c2: decisions every game advances per step (one launch)")
     ap.add_argument("--stack", type=int, default=0, help="per-lane scratch stack bytes (0 = library default)")
     ap.add_argument("--no-cpu", action="store_true")
-    ap.add_argument("--cpu-sample", type=int, default=8192)
+    ap.add_argument("--cpu-sample", type=int, default=32768)
     ap.add_argument("--cpu-threads", type=int, default=16)
     args = ap.parse_args(argv)
     if args.steps is None:
-        args.steps = 100 if args.workload == "c2" else 5
+        args.steps = 12 if args.workload == "c2" else 5
     if args.warmup is None:
-        args.warmup = 20 if args.workload == "c2" else 1
+        args.warmup = 3 if args.workload == "c2" else 1
     return args
 
 
@@ -203,6 +204,8 @@ def run_rank(args):
 
     if args.workload == "c2":
         line = bench_c2(args, rank, world, local_rank, fake, barrier, all_sum, all_max)
+    elif args.workload == "rollout":
+        line = bench_rollout(args, rank, world, local_rank, barrier, all_sum, all_max)
     else:
         line = bench_c4(args, rank, world, local_rank, barrier, all_sum, all_max)
     # ranks that really took part in the collective (the job's size as RCCL saw it)
@@ -292,6 +295,64 @@ def bench_c2(args, rank, world, local_rank, fake, barrier, all_sum, all_max):
     if not args.no_cpu and world == 1 and rank == 0 and not fake:
         line["cpu_baseline"] = cpu_baseline(args.cpu_sample, 200, args.cpu_threads)
     return line
+
+
+def bench_rollout(args, rank, world, local_rank, barrier, all_sum, all_max):
+    """Whole games: one step = --games fresh games (reset + monsoon_rollout to a winner, a fault or 200 decisions), on a
+    named deck or on C5's per-game random decks (109 observable cards, extended-record build).  For profiling the
+    configurations other than C2 (S12: short, divergent games; random decks: worst-case card divergence)."""
+    from monsoon_amd.cards import CARD_IDS, deck_indices
+    from monsoon_amd.engine import BatchEngine
+    n = args.games
+    random_decks = args.deck == "random"
+    eng = BatchEngine(n, device=local_rank, lanes_per_game=args.lanes, stack_bytes=args.stack, extended=random_decks)
+    if random_decks:
+        pool = np.array([i for i, c in enumerate(CARD_IDS) if c not in ("up01", "up02", "up03")], dtype=np.uint8)
+        pairs = np.zeros((n, 2, 12), dtype=np.uint8)
+        for g in range(n):
+            rs = np.random.RandomState((g + rank * n) ^ 0x9E3779B9)
+            pairs[g, 0], pairs[g, 1] = rs.choice(pool, 12, replace=False), rs.choice(pool, 12, replace=False)
+    else:
+        deck = deck_indices(args.deck)
+        pairs = np.stack([deck, deck])[None]
+    w = np.random.RandomState(2024).uniform(0, 1, (2, 10))
+
+    def one(step):
+        m = np.zeros(n, dtype=[("p1", "<i4"), ("p2", "<i4"), ("seed", "<u4"), ("deck", "<u4")])
+        m["p2"] = 1
+        m["seed"] = np.arange(n) + (step * world + rank) * n
+        if random_decks:
+            m["deck"] = np.arange(n)
+        return eng.rollout(w, m, pairs, 200, want_results=True)
+
+    for k in range(args.warmup):
+        one(k)
+    eng.reset_stats()
+    barrier()
+    t0 = time.perf_counter()
+    decisions = 0
+    for k in range(args.steps):
+        _, _, steps = one(args.warmup + k)
+        decisions += int(steps.sum())
+    barrier()
+    dt = time.perf_counter() - t0
+    st = eng.stats()
+    kms, launches = eng.kernel_time()
+    tot_look, tot_dec = all_sum([st["lookahead_steps"], decisions])
+    max_dt = all_max(dt)
+    return {
+        "metric": METRIC, "value": tot_look / max_dt, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": 1000.0 * max_dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "u8/i16 state, f64 draw+score", "data": "synthetic",
+        "config": {"workload": f"rollout: {n} fresh games per step on deck {args.deck}, played to the end (reset + upload + one k_play launch + "
+                               f"collect)", "games_per_gpu": n, "lanes_per_game": eng.variant()[0], "extended_record": random_decks},
+        "decisions_per_s": tot_dec / max_dt, "lookahead_per_decision": tot_look / max(tot_dec, 1),
+        "mean_game_length": decisions / (n * args.steps), "faults": st["faults"], "capacity_faults": st["capacity_faults"],
+        "lookahead_capacity_faults": st["lookahead_capacity_faults"],
+        "roofline": {"bound": "hbm", "achieved": (BYTES_LOOKAHEAD * st["lookahead_steps"] + BYTES_COMMIT * decisions) / max(kms / 1000.0, 1e-9) / 1e9,
+                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "traffic": None, "kernel": "k_play", "avg_launch_ms": kms / max(launches, 1),
+                     "launches": launches},
+    }
 
 
 def bench_c4(args, rank, world, local_rank, barrier, all_sum, all_max):

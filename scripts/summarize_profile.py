@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
-"""Condense a scripts/profile_r1.sh output directory (gpurun_out/prof_<tag>/) into
+"""Condense a scripts/profile_r2.sh output directory (gpurun_out/prof_<tag>/) into
 profiles/<tag>_*.{csv,json,md}: the rocprofv3 --kernel-trace --stats table, per-dispatch means of
-the PMC passes for k_decide, and the HBM traffic figure bench.py reports as roofline.traffic.
+the PMC passes for the hot kernel (k_play; k_decide in round 1), and the HBM traffic figure bench.py reports as
+roofline.traffic (labelled with the configuration it was measured on).
 
 HBM bytes per launch = (2 * FETCH_SIZE + WRITE_SIZE) * 1024   (MI355X_MICROARCH.md, HBM section:
 FETCH_SIZE/WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reads half of a wide coalesced stream, so
@@ -15,9 +16,15 @@ import os
 import shutil
 import sys
 
+def HOT(name):
+    return "k_play" in name or "k_decide" in name
+
+
 tag = sys.argv[1]
 src = sys.argv[2] if len(sys.argv) > 2 else f"gpurun_out/prof_{tag}"
 os.makedirs("profiles", exist_ok=True)
+args_file = os.path.join(src, "bench_args.txt")
+bench_args = open(args_file).read().strip() if os.path.exists(args_file) else "--steps 40 --warmup 20 --no-cpu"
 stats = glob.glob(f"{src}/trace/**/*_kernel_stats.csv", recursive=True)[0]
 shutil.copy(stats, f"profiles/{tag}_kernel_stats.csv")
 means = {}
@@ -28,7 +35,7 @@ for name in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_sq2"):
     acc = collections.defaultdict(lambda: [0, 0.0])
     meta = {}
     for r in csv.DictReader(open(files[0])):
-        if "k_decide" in r["Kernel_Name"]:
+        if HOT(r["Kernel_Name"]):
             a = acc[r["Counter_Name"]]
             a[0] += 1
             a[1] += float(r["Counter_Value"])
@@ -36,14 +43,14 @@ for name in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_sq2"):
     for k, (n, v) in acc.items():
         means[k] = {"dispatches": n, "mean_per_dispatch": v / n}
     means["_dispatch"] = meta
-kd = [r for r in csv.DictReader(open(stats)) if "k_decide" in r["Name"]][0]
+kd = [r for r in csv.DictReader(open(stats)) if HOT(r["Name"])][0]
 # per-dispatch durations from the kernel trace: the last `launches` dispatches are bench.py's timed region
 trace_csv = glob.glob(f"{src}/trace/**/*_kernel_trace.csv", recursive=True)
 timed_avg_ns = None
 durs = []
 if trace_csv:
     for r in csv.DictReader(open(trace_csv[0])):
-        if "k_decide" in r["Kernel_Name"]:
+        if HOT(r["Kernel_Name"]):
             durs.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"])))
     durs.sort()
 bench = {}
@@ -60,19 +67,20 @@ if "FETCH_SIZE" in means and "WRITE_SIZE" in means:
     out["hbm_bytes_per_launch"] = (2 * means["FETCH_SIZE"]["mean_per_dispatch"] + means["WRITE_SIZE"]["mean_per_dispatch"]) * 1024
     json.dump({"bytes_per_launch": out["hbm_bytes_per_launch"], "source": f"profiles/{tag}_summary.json",
                "formula": "(2*FETCH_SIZE + WRITE_SIZE) * 1024, separate --pmc passes, mean over k_decide dispatches",
-               "config": "bench.py --steps 40 --warmup 20 (65536 games)"}, open("profiles/traffic.json", "w"), indent=1)
+               "measured_on": f"bench.py {bench_args} (65536 games), rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs, {tag}"},
+              open("profiles/traffic.json", "w"), indent=1)
 json.dump(out, open(f"profiles/{tag}_summary.json", "w"), indent=1)
 with open(f"profiles/{tag}_summary.md", "w") as f:
-    f.write(f"# rocprofv3 summary {tag}: `bench.py --steps 40 --warmup 20 --no-cpu` (65 536 games, one MI355X)\n\n")
+    f.write(f"# rocprofv3 summary {tag}: `bench.py {bench_args}` (65 536 games, one MI355X)\n\n")
     f.write(f"kernel-trace --stats: `{kd['Name']}` calls {kd['Calls']}, average {float(kd['AverageNs'])/1e6:.3f} ms "
             f"(min {float(kd['MinNs'])/1e6:.3f}, max {float(kd['MaxNs'])/1e6:.3f}), {kd['Percentage']} % of GPU time\n\n")
     if bench:
         r = bench["roofline"]
         f.write(f"bench.py under the trace: {bench['value']/1e6:.1f} M env-steps/s, HIP-event average launch {r['avg_launch_ms']:.3f} ms "
-                f"over the {r['launches']} timed launches (the stats row above also counts the 20 warm-up launches, "
+                f"over the {r['launches']} timed launches (the stats row above also counts the warm-up launches, "
                 f"which are early-game rounds with fewer legal actions; the kernel-trace average over the SAME last "
                 f"{r['launches']} dispatches is {timed_avg_ns/1e6:.3f} ms)\n\n")
-    f.write("| counter | mean per k_decide dispatch |\n|---|---|\n")
+    f.write("| counter | mean per hot-kernel dispatch |\n|---|---|\n")
     for k, v in means.items():
         if k != "_dispatch":
             f.write(f"| {k} | {v['mean_per_dispatch']:.4g} |\n")
