@@ -159,6 +159,12 @@ int monsoon_decide(monsoon_t* h, const double* weights, uint8_t* out_action, dou
 int monsoon_rollout(monsoon_t* h, const double* weights, int32_t n_individuals, const monsoon_match* matches,
                     int32_t n_matches, const uint8_t* deck_pairs, int32_t n_decks, int32_t max_turns,
                     int32_t* out_counts, int8_t* out_results, int32_t* out_steps);
+/* Fault code of every game of the last completed monsoon_rollout, out[n_matches] (same meaning as monsoon_game_faults:
+ * the fault that stopped the game, else the first capacity code one of its look-aheads hit).  Codes >= 16 are limits
+ * of this build's record, not reference behaviour (the exception the reference swallows at evo/fitness.py:170-174,
+ * 208-210 is code 1): such games are replayed on a build with a larger record -- libmonsoon_hip_ext.so ->
+ * libmonsoon_hip_big.so, as monsoon_amd/fitness.py does -- and their rows of the result replaced. */
+int monsoon_rollout_faults(monsoon_t* h, uint8_t* out, int32_t n_matches);
 
 /* Diagnostics: 192 raw counter words (words 0-4 back monsoon_get_stats; a profiling build (-DMSB_PROF=1,
  * scripts only) adds k_decide phase cycles at 8..15, per-function cycles / calls at 32..63 / 64..95, last-launch

@@ -11,6 +11,9 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmonsoon_hip.so")
 # same source built with -DMSB_EXT=1: larger per-game record, needed by decks holding ua20 or b005
 LIB_PATH_EXT = os.path.join(_HERE, "libmonsoon_hip_ext.so")
+# -DMSB_EXT=2: the large extended record (254 entity slots): the games whose nested b005 memories outgrow the extended
+# record are replayed here (monsoon_amd/fitness.py)
+LIB_PATH_BIG = os.path.join(_HERE, "libmonsoon_hip_big.so")
 
 OK, ERR_ARG, ERR_DEVICE, ERR_STATE = 0, 1, 2, 3
 NUM_ACTIONS = 156
@@ -70,6 +73,7 @@ SIGNATURES = {
     "monsoon_rollout": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p, ctypes.c_int32,
                                        ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p,
                                        ctypes.c_void_p]),
+    "monsoon_rollout_faults": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32]),
     "monsoon_upload_weights": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32]),
     "monsoon_assign_players": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
     "monsoon_decide_round_dev": (ctypes.c_int, [ctypes.c_void_p]),
@@ -84,10 +88,11 @@ SIGNATURES = {
 
 
 def load(extended=False):
-    """Load the HIP library (fails loudly when it has not been built)."""
+    """Load the HIP library (fails loudly when it has not been built).  extended: False / True / 2 (the large record)."""
+    extended = int(extended)
     if extended in _libs:
         return _libs[extended]
-    path = LIB_PATH_EXT if extended else LIB_PATH
+    path = (LIB_PATH, LIB_PATH_EXT, LIB_PATH_BIG)[extended]
     if not extended and os.environ.get("MONSOON_LIB"):
         path = os.environ["MONSOON_LIB"]   # development knob: A/B another build of the same ABI (scripts/ab_bench.sh)
     if not os.path.exists(path):
@@ -95,7 +100,7 @@ def load(extended=False):
                            "or `make -C monsoon_amd/csrc all` (there is no CPU fallback)")
     lib = ctypes.CDLL(path)
     for name, (res, args) in SIGNATURES.items():
-        if path not in (LIB_PATH, LIB_PATH_EXT) and not hasattr(lib, name):
+        if path not in (LIB_PATH, LIB_PATH_EXT, LIB_PATH_BIG) and not hasattr(lib, name):
             continue              # an older build loaded through MONSOON_LIB may lack newer diagnostics entry points
         fn = getattr(lib, name)   # AttributeError if the ABI and this binding drift apart
         fn.restype = res

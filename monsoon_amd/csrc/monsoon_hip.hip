@@ -28,7 +28,11 @@ namespace {
 // address 0 (these kernels declare no static __shared__), interleaved across lanes in 16-byte granules.
 // ------------------------------------------------------------------------------------------------
 // games per 64-thread block in the API kernels: the extended record is too large for 64 LDS columns
-#if defined(MSB_EXT) && MSB_EXT
+#if defined(MSB_API_LANES)
+constexpr int API_LANES = MSB_API_LANES;   // probes only (scripts/probe/divergence2.sh)
+#elif defined(MSB_EXT) && MSB_EXT == 2
+constexpr int API_LANES = 8;
+#elif defined(MSB_EXT) && MSB_EXT
 constexpr int API_LANES = 16;
 #else
 constexpr int API_LANES = 64;
@@ -254,7 +258,7 @@ __global__ void k_assign(DevBuffers b, int n, const int32_t* p1, const int32_t* 
   b.meta[g].match = (uint32_t)(match_base + g);
 }
 
-__global__ void k_collect(DevBuffers b, int n, int32_t* counts, int8_t* results, int32_t* steps) {
+__global__ void k_collect(DevBuffers b, int n, int32_t* counts, int8_t* results, int32_t* steps, uint8_t* faults) {
   int g = blockIdx.x * blockDim.x + threadIdx.x;
   const bool on = g < n;
   GameMeta m = b.meta[on ? g : 0];
@@ -279,6 +283,7 @@ __global__ void k_collect(DevBuffers b, int n, int32_t* counts, int8_t* results,
   if (!on) return;
   if (results) results[m.match] = (int8_t)r;
   if (steps) steps[m.match] = m.steps;
+  if (faults) faults[m.match] = m.fault ? m.fault : m.la_fault;
 }
 
 // monsoon_debug_build / monsoon_debug_op (diagnostics; scenario tests): ONE lane runs scenario.inc on game g.  The
@@ -426,7 +431,8 @@ struct monsoon {
   // rollout result buffers, grown on demand and kept for the life of the handle
   int32_t* d_counts = nullptr;
   size_t counts_cap = 0;
-  int8_t* d_results = nullptr;
+  int8_t* d_results = nullptr;    // [matches_cap] results, then [matches_cap] fault codes (monsoon_rollout_faults)
+  size_t rollout_matches = 0;     // matches of the last monsoon_rollout
   int32_t* d_steps = nullptr;
   size_t matches_cap = 0;
   // kernel timing: event pairs are created once and reused
@@ -487,7 +493,9 @@ static const VariantOps* default_variant() {
 extern "C" {
 
 int monsoon_version(void) {
-#if defined(MSB_EXT) && MSB_EXT
+#if defined(MSB_EXT) && MSB_EXT == 2
+  return 0x30002;   // bits 16 + 17: the large extended record (254 entity slots)
+#elif defined(MSB_EXT) && MSB_EXT
   return 0x10002;   // bit 16: extended record
 #else
   return 2;
@@ -1159,11 +1167,13 @@ int monsoon_rollout(monsoon_t* h, const double* weights, int32_t n_individuals, 
     h->d_results = nullptr;
     h->d_steps = nullptr;
     h->matches_cap = 0;
-    HIP_TRY(h, hipMalloc(&h->d_results, (size_t)n_matches));
+    HIP_TRY(h, hipMalloc(&h->d_results, 2 * (size_t)n_matches));
     HIP_TRY(h, hipMalloc(&h->d_steps, (size_t)n_matches * 4));
     h->matches_cap = (size_t)n_matches;
   }
   HIP_TRY(h, hipMemsetAsync(h->d_counts, 0, (size_t)n_individuals * 12, h->stream));
+  h->rollout_matches = 0;
+  uint8_t* d_faults = (uint8_t*)h->d_results + h->matches_cap;
   int cap = h->cfg.max_games;
   std::vector<uint32_t> seeds;
   std::vector<uint8_t> decks;
@@ -1187,7 +1197,7 @@ int monsoon_rollout(monsoon_t* h, const double* weights, int32_t n_individuals, 
     // one launch plays the whole batch to the end
     rc = launch_play(h, n, max_turns, max_turns + 1, 0, true);
     if (rc) return rc;
-    hipLaunchKernelGGL(k_collect, dim3((n + 255) / 256), dim3(256), 0, h->stream, h->b, n, h->d_counts, h->d_results, h->d_steps);
+    hipLaunchKernelGGL(k_collect, dim3((n + 255) / 256), dim3(256), 0, h->stream, h->b, n, h->d_counts, h->d_results, h->d_steps, d_faults);
     HIP_TRY(h, hipGetLastError());
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     rc = drain_timing(h);
@@ -1198,6 +1208,18 @@ int monsoon_rollout(monsoon_t* h, const double* weights, int32_t n_individuals, 
   for (size_t i = 0; i < counts.size(); i++) out_counts[i] += counts[i];
   if (out_results) HIP_TRY(h, hipMemcpy(out_results, h->d_results, (size_t)n_matches, hipMemcpyDeviceToHost));
   if (out_steps) HIP_TRY(h, hipMemcpy(out_steps, h->d_steps, (size_t)n_matches * 4, hipMemcpyDeviceToHost));
+  h->rollout_matches = (size_t)n_matches;
+  return MONSOON_OK;
+}
+
+int monsoon_rollout_faults(monsoon_t* h, uint8_t* out, int32_t n_matches) {
+  if (!h || !out) return MONSOON_ERR_ARG;
+  if (n_matches <= 0 || (size_t)n_matches != h->rollout_matches) {
+    h->err = "monsoon_rollout_faults: n_matches is not the size of the last completed monsoon_rollout";
+    return MONSOON_ERR_ARG;
+  }
+  HIP_TRY(h, hipSetDevice(h->device));
+  HIP_TRY(h, hipMemcpy(out, (uint8_t*)h->d_results + h->matches_cap, (size_t)n_matches, hipMemcpyDeviceToHost));
   return MONSOON_OK;
 }
 

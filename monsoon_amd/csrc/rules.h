@@ -144,29 +144,65 @@ constexpr int AT_PLAYER = 256;  // + PlayerOrder (above every entity slot id)
 
 enum : int { SH_FRONT, SH_BEHIND, SH_SIDE, SH_ROW, SH_COLUMN, SH_BORDERING, SH_SURROUNDING };
 
+#if defined(MSB_CAP_DEPTH)
+constexpr int MAX_DEPTH = MSB_CAP_DEPTH;   // capacity studies
+#else
 constexpr int MAX_DEPTH = 40;
+#endif
 
 // Which rules-core functions are inlined into their callers was settled by same-box A/B runs (scripts/ab_env.sh)
 // measured (same-box A/B, 65 536 games): new_entity + set_path + calculate_front_line inlined +2.4 %;
-// entity_deal_damage inlined +0.6 %; player_play inlined -15 %
+// entity_deal_damage inlined +0.6 %; player_play inlined -15 % in round 1's k_decide, +2 % in round 2's k_play (1 437-1 450 ->
+// 1 474 M env-steps/s; step_impl inlined as well: 1 462; to_next_turn inlined: 1 380; destroy inlined: 1 453)
+#ifndef MSB_A_NEWENT
 #define MSB_A_NEWENT MSB_INL
+#endif
+#ifndef MSB_A_SETPATH
 #define MSB_A_SETPATH MSB_INL
+#endif
+#ifndef MSB_A_FRONT
 #define MSB_A_FRONT MSB_INL
-#define MSB_A_PLAY MSB_NOINLINE
+#endif
+#ifndef MSB_A_PLAY
+#define MSB_A_PLAY MSB_INL
+#endif
 // second batch: get_targets inlined +7.8 %, shape_targets +5 %, entity_deal_damage +1.6 %, draw +1.2 %, destroy -3 %
+#ifndef MSB_A_DAMAGE
 #define MSB_A_DAMAGE MSB_INL
+#endif
+#ifndef MSB_A_TARGETS
 #define MSB_A_TARGETS MSB_INL
+#endif
+#ifndef MSB_A_DRAW
 #define MSB_A_DRAW MSB_INL
+#endif
+#ifndef MSB_A_DESTROY
 #define MSB_A_DESTROY MSB_NOINLINE
+#endif
+#ifndef MSB_A_SHAPE
 #define MSB_A_SHAPE MSB_INL
+#endif
 // third batch (no gain, left out-of-line): shape_tiles +0.4 %, shuffle/sorted_head 0, legal_mask_v +0.2 %,
 // command/teleport/push_pull/force_attack/spawn/respawn +0.8 %; flip + to_next_turn inlined -8.5 %, ability_spell -18 %.
 // One non-inlined function per card instead of one switch function (abilities.inc): +3 %.
+#ifndef MSB_A_TILES
 #define MSB_A_TILES MSB_NOINLINE
+#endif
+#ifndef MSB_A_SHUFFLE
 #define MSB_A_SHUFFLE MSB_NOINLINE
+#endif
+#ifndef MSB_A_LEGAL
 #define MSB_A_LEGAL MSB_NOINLINE
+#endif
+#ifndef MSB_A_MISC
 #define MSB_A_MISC MSB_NOINLINE
+#endif
+#ifndef MSB_A_STEP
+#define MSB_A_STEP MSB_NOINLINE
+#endif
+#ifndef MSB_A_TURN
 #define MSB_A_TURN MSB_NOINLINE
+#endif
 
 template <class M>
 struct Engine {
@@ -503,39 +539,45 @@ struct Engine {
   // A free entity slot: not on the board and not referenced since the step began.  The standard record keeps the
   // set in one 32-bit word; the extended record (up to 128 slots) in four.
   struct Bits {
-    uint64_t lo, hi;
-    MSB_HD MSB_INL bool has(int i) const { return ((i < 64 ? lo >> i : hi >> (i - 64)) & 1ull) != 0; }
-    MSB_HD MSB_INL void add(int i) {
-      if (i < 64) lo |= 1ull << i;
-      else hi |= 1ull << (i - 64);
+    static constexpr int NW = NUM_ENT > 128 ? 4 : 2;
+    uint64_t w[NW];
+    MSB_HD MSB_INL static Bits none() {
+      Bits b;
+      for (int i = 0; i < NW; i++) b.w[i] = 0;
+      return b;
     }
-    MSB_HD MSB_INL bool any() const { return (lo | hi) != 0; }
+    MSB_HD MSB_INL bool has(int i) const { return ((w[i >> 6] >> (i & 63)) & 1ull) != 0; }
+    MSB_HD MSB_INL void add(int i) { w[i >> 6] |= 1ull << (i & 63); }
+    MSB_HD MSB_INL void del(int i) { w[i >> 6] &= ~(1ull << (i & 63)); }
+    MSB_HD MSB_INL bool any() const {
+      uint64_t a = 0;
+      for (int i = 0; i < NW; i++) a |= w[i];
+      return a != 0;
+    }
     MSB_HD MSB_INL int pop() {   // lowest member, removed
-      if (lo) {
-        int i = __builtin_ctzll(lo);
-        lo &= lo - 1;
-        return i;
-      }
-      int i = __builtin_ctzll(hi);
-      hi &= hi - 1;
-      return 64 + i;
+      for (int i = 0; i < NW - 1; i++)
+        if (w[i]) {
+          int b = __builtin_ctzll(w[i]);
+          w[i] &= w[i] - 1;
+          return 64 * i + b;
+        }
+      int b = __builtin_ctzll(w[NW - 1]);
+      w[NW - 1] &= w[NW - 1] - 1;
+      return 64 * (NW - 1) + b;
     }
   };
+  MSB_HD MSB_INL static int used_off(int word) { return word == 0 ? H_USED : X_USED_HI + 4 * (word - 1); }
   MSB_HD MSB_INL Bits used_mask() const {
-    Bits u{m.ld32(H_USED), 0};
-    if (NUM_ENT > 32) {
-      u.lo |= (uint64_t)m.ld32(X_USED_HI) << 32;
-      u.hi = (uint64_t)m.ld32(X_USED_HI + 4) | ((uint64_t)m.ld32(X_USED_HI + 8) << 32);
-    }
+    Bits u = Bits::none();
+    u.w[0] = m.ld32(H_USED);
+    if (NUM_ENT > 32)
+      for (int k = 1; k < USED_WORDS; k++) u.w[k >> 1] |= (uint64_t)m.ld32(used_off(k)) << (32 * (k & 1));
     return u;
   }
   MSB_HD MSB_INL void set_used_mask(Bits u) {
-    m.st32(H_USED, (uint32_t)u.lo);
-    if (NUM_ENT > 32) {
-      m.st32(X_USED_HI, (uint32_t)(u.lo >> 32));
-      m.st32(X_USED_HI + 4, (uint32_t)u.hi);
-      m.st32(X_USED_HI + 8, (uint32_t)(u.hi >> 32));
-    }
+    m.st32(H_USED, (uint32_t)u.w[0]);
+    if (NUM_ENT > 32)
+      for (int k = 1; k < USED_WORDS; k++) m.st32(used_off(k), (uint32_t)(u.w[k >> 1] >> (32 * (k & 1))));
   }
   MSB_HD MSB_INL int alloc_entity() {
     if (NUM_ENT <= 32) {
@@ -558,10 +600,10 @@ struct Engine {
     return e;
   }
   MSB_HD MSB_INL int alloc_entity_ext() {   // -1 = no free slot
-    static_assert(NUM_ENT <= 32 || (NUM_ENT % 32 == 0 && NUM_ENT <= 128), "extended record: up to four words of slot bits");
-    for (int w = 0; w < NUM_ENT / 32; w++) {
-      const int off = w == 0 ? H_USED : X_USED_HI + 4 * (w - 1);
+    for (int w = 0; w < USED_WORDS; w++) {
+      const int off = used_off(w);
       uint32_t used = m.ld32(off);
+      if (w == USED_WORDS - 1 && (NUM_ENT & 31)) used |= ~0u << (NUM_ENT & 31);   // ids past the last slot are never free
       if (used != 0xffffffffu) {
         int b = __builtin_ctz(~used);
         m.st32(off, used | (1u << b));
@@ -582,8 +624,7 @@ struct Engine {
         int h = m.ld8(o + W_BOARD + t);
         if (h >= NUM_ENT || m.ld8(E_HOME + h) != (HOME_COPY | w)) continue;
         m.st8(o + W_BOARD + t, SLOT_MISSING);
-        if (h < 64) u.lo &= ~(1ull << h);
-        else u.hi &= ~(1ull << (h - 64));
+        u.del(h);
         any = true;
       }
       if (any) {
@@ -614,20 +655,20 @@ struct Engine {
   MSB_HD MSB_INL void begin_step() {
     MSB_SCOPE(PS_BEGIN_STEP);
     // one shift per tile, no compare: an empty tile (0xFF) sets the top bit, which is not an entity slot
-    static_assert((SLOT_NONE & 31) >= 28 && NUM_ENT <= 128, "the empty marker must map outside the slot bits");
-    Bits used{0, 0};
+    static_assert((SLOT_NONE & 31) >= 28, "the empty marker must map outside the slot bits");
+    Bits used = Bits::none();
     for (int y = 0; y < 5; y++) {
       uint32_t row = board_row(y);
       if (NUM_ENT <= 32) {
-        for (int x = 0; x < 4; x++) used.lo |= 1u << ((row >> (8 * x)) & 31u);
+        for (int x = 0; x < 4; x++) used.w[0] |= 1u << ((row >> (8 * x)) & 31u);
       } else {
         for (int x = 0; x < 4; x++) {
           uint32_t sl = (row >> (8 * x)) & 0xffu;
-          if (sl != (uint32_t)SLOT_NONE) used.add((int)(sl & 127u));
+          if (sl < (uint32_t)NUM_ENT) used.add((int)sl);
         }
       }
     }
-    if (NUM_ENT <= 32) used.lo &= (1ull << (NUM_ENT & 31)) - 1ull;
+    if (NUM_ENT <= 32) used.w[0] &= (1ull << (NUM_ENT & 31)) - 1ull;
     // a hand/deck entry aliasing an entity that has left the board keeps that object's last strength
     if (m.ld8(H_OBSFAULT) & GF_ALIAS) {
       for (int o = 0; o < 2; o++) {
@@ -698,6 +739,7 @@ struct Engine {
     static_assert(OFF_BOARD % 4 == 0 && OFF_TRIG % 4 == 0 && OFF_WORLD % 4 == 0, "word-wise swaps");
     for (int k = 0; k < 5; k++) swap32(OFF_BOARD + 4 * k, o + W_BOARD + 4 * k);
     for (int k = 0; k < 5; k++) swap32(OFF_TRIG + 4 * k, o + W_TRIG + 4 * k);
+    if (TRIG_WIDE) swap32(X_TRIGSRC, o + W_TRIGSRC);
     swap8(H_TOPLAY, o + W_TOPLAY);
     swap8(H_TRIG_N, o + W_TRIG_N);
     swap8(H_RESOLVING, o + W_RESOLVING);
@@ -808,8 +850,8 @@ struct Engine {
         lists |= 1u << L;
         int n = rem_n(L);
         for (int k = 0; k < n; k++) {
-          int r = rem_get(L, k) & 127;
-          if (!used.has(r)) {
+          int r = rem_get(L, k);
+          if (r < NUM_ENT && !used.has(r)) {
             used.add(r);
             todo.add(r);
           }
@@ -822,9 +864,8 @@ struct Engine {
         const int o = world_off(H);
         int tn = m.ld8(o + W_TRIG_N);
         for (int t = 0; t < 20 + tn; t++) {
-          int v = t < 20 ? m.ld8(o + W_BOARD + t) : (m.ld8(o + W_TRIG + t - 20) & 0x7f);
-          if (t < 20 && (v == SLOT_NONE || v == SLOT_MISSING)) continue;
-          v &= 127;
+          int v = t < 20 ? m.ld8(o + W_BOARD + t) : (m.ld8(o + W_TRIG + t - 20) & TRIG_SLOT);
+          if (v >= NUM_ENT) continue;   // SLOT_NONE / SLOT_MISSING
           if (!used.has(v)) {
             used.add(v);
             todo.add(v);
@@ -896,13 +937,14 @@ struct Engine {
       int v = src ? m.ld8(so + W_TRIG + i) : m.ld8(OFF_TRIG + i);
       int nv = -1;
       for (int t = 0; t < 20; t++)
-        if ((src ? m.ld8(so + W_BOARD + t) : board_at(t)) == (v & 0x7f)) nv = m.ld8(o + W_BOARD + t);
+        if ((src ? m.ld8(so + W_BOARD + t) : board_at(t)) == (v & TRIG_SLOT)) nv = m.ld8(o + W_BOARD + t);
       if (nv < 0 || nv >= NUM_ENT) {
         m.st8(o + W_PARTIAL, 1);
         nv = 0;
       }
-      m.st8(o + W_TRIG + i, nv | (v & 0x80));
+      m.st8(o + W_TRIG + i, nv | (TRIG_WIDE ? 0 : (v & 0x80)));
     }
+    if (TRIG_WIDE) m.st32(o + W_TRIGSRC, src ? m.ld32(so + W_TRIGSRC) : m.ld32(X_TRIGSRC));
     return w;
   }
   // copy.deepcopy of a memory list (the list object, its entities, their own memories, and -- through entity.player
@@ -1228,15 +1270,28 @@ struct Engine {
       set_fault(FAULT_TRIG_STACK);
       return;
     }
-    m.st8(OFF_TRIG + n, e | (src ? 0x80 : 0));
+    trig_put(n, e, src);
     m.st8(H_TRIG_N, n + 1);
   }
+  // entry i of the trigger stack: the slot in the byte, has_source in its top bit -- or, where slot ids need all eight
+  // bits (TRIG_WIDE), in bit i of X_TRIGSRC
+  MSB_HD MSB_INL void trig_put(int i, int e, bool src) {
+    if (TRIG_WIDE) {
+      m.st8(OFF_TRIG + i, e);
+      uint32_t f = m.ld32(X_TRIGSRC);
+      m.st32(X_TRIGSRC, src ? f | (1u << i) : f & ~(1u << i));
+    } else
+      m.st8(OFF_TRIG + i, e | (src ? 0x80 : 0));
+  }
+  MSB_HD MSB_INL int trig_slot(int i) const { return m.ld8(OFF_TRIG + i) & TRIG_SLOT; }
+  MSB_HD MSB_INL bool trig_src(int i) const { return TRIG_WIDE ? ((m.ld32(X_TRIGSRC) >> i) & 1u) != 0 : (m.ld8(OFF_TRIG + i) & 0x80) != 0; }
   MSB_HD MSB_INL void pop_trigger() {
     int n = m.ld8(H_TRIG_N);
     if (n == 0 || m.ld8(H_RESOLVING)) return;
-    int v = m.ld8(OFF_TRIG + n - 1);
+    int e = trig_slot(n - 1);
+    bool src = trig_src(n - 1);
     m.st8(H_TRIG_N, n - 1);
-    run_ability(v & 0x7f, -1, PK_NONE, (v & 0x80) != 0);
+    run_ability(e, -1, PK_NONE, src);
   }
   // wrapped activate_ability.  subj >= 0: entity slot.  subj < 0: a spell, spell_card/spell_owner
   // passed in `spell`.  The trailing pop_trigger() is a tail call in the reference, hence a loop.
@@ -1268,12 +1323,11 @@ struct Engine {
       m.st8(H_RESOLVING, 0);
       int n = m.ld8(H_TRIG_N);
       if (n == 0) break;
-      int v = m.ld8(OFF_TRIG + n - 1);
+      e = trig_slot(n - 1);
+      src = trig_src(n - 1);
       m.st8(H_TRIG_N, n - 1);
-      e = v & 0x7f;
       spell = -1;
       pos_pk = PK_NONE;
-      src = (v & 0x80) != 0;
     }
     m.st8(H_DEPTH, d);
   }
@@ -2007,7 +2061,7 @@ struct Engine {
     MSB_POSTCALL(PS_STEP);
     return r_;
   }
-  MSB_HD MSB_NOINLINE int step_impl(int action) {
+  MSB_HD MSB_A_STEP int step_impl(int action) {
     MSB_SCOPE(PS_STEP);
     int result = 0;
     begin_step();

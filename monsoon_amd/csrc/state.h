@@ -19,7 +19,11 @@
 
 namespace msb {
 
-#if defined(MSB_EXT) && MSB_EXT
+#if defined(MSB_CAP_ENT)
+constexpr int NUM_ENT = MSB_CAP_ENT;   // capacity studies (scripts/c5_capacity.py)
+#elif defined(MSB_EXT) && MSB_EXT == 2
+constexpr int NUM_ENT = 254;  // the LARGE record: every slot id a byte can name (0xFE / 0xFF are markers)
+#elif defined(MSB_EXT) && MSB_EXT
 constexpr int NUM_ENT = 128;  // 20 tiles + transient + b005's remembered copies + the entities of frozen world snapshots
 #else
 constexpr int NUM_ENT = 28;    // 20 tiles + 8 transient (dead / displaced / spawned this step)
@@ -31,8 +35,15 @@ constexpr int DECK_SIZE = 12;  // cards per deck at construction (games/stormbou
 // single-use deck cards (cards/ua20.py:27-32) and for b005's remembered deep copies (cards/b005.py:14-33).
 #if defined(MSB_EXT) && MSB_EXT
 constexpr int DECK_CAP = 32;
+#if defined(MSB_CAP_REM)       // capacity studies (scripts/c5_capacity.py)
+constexpr int REM_LISTS = MSB_CAP_REM, WORLD_CAP = MSB_CAP_WORLD;
+#elif MSB_EXT == 2             // the LARGE record: where monsoon_rollout replays the games the extended record cannot hold
+constexpr int REM_LISTS = 32, WORLD_CAP = 16;
+#else
 constexpr int REM_LISTS = 16;  // memory lists (one per b005 with a pending memory, nested ones included)
 constexpr int WORLD_CAP = 8;   // frozen world snapshots alive at once (see below)
+#endif
+static_assert(REM_LISTS <= 32 && WORLD_CAP < 32, "rem_collect keeps the live lists and worlds in 32-bit sets");
 #else
 constexpr int DECK_CAP = 12;
 constexpr int REM_LISTS = 0;
@@ -57,6 +68,7 @@ constexpr int W_TOPLAY = 40, W_TRIG_N = 41, W_RESOLVING = 42, W_PHASE = 43, W_CP
 constexpr int W_BASE = 48;        // 2 x i16
 constexpr int W_RNG = 52;         // u32 absolute position in the game's stream (block * 624 + index)
 constexpr int W_PARTIAL = 56;     // the snapshot is incomplete (entity slots ran out, or were taken back): entering it faults
+constexpr int W_TRIGSRC = 60;     // u32, records with more than 128 slots only: the has_source bits of the trigger stack
 constexpr int WORLD_BYTES = 64;
 // Entity slots are a CACHE for the contents of frozen worlds: a world is only ever read if one of its entities is
 // restored to the real board and acts before the next flip -- rare -- so a snapshot that does not fit is not an
@@ -89,7 +101,7 @@ constexpr int H_OBSFAULT = 22;  // game flags: b0 a deck holds up01/up02/up03 (o
 constexpr int GF_OBSFAULT = 1, GF_ALIAS = 2;
 constexpr int H_RNGOVER = 23;   // set when a step wanted more than the two resident blocks
 constexpr int OFF_BOARD = 24;   // 20 x u8 slot
-constexpr int OFF_TRIG = 44;    // TRIG_CAP x u8 (slot | has_source<<7)
+constexpr int OFF_TRIG = 44;    // TRIG_CAP x u8 (slot | has_source<<7; with more than 128 slots the flags move to X_TRIGSRC)
 constexpr int H_RNGCUR = 64;    // u64 address of the current block of tempered outputs
 constexpr int H_RNGNXT = 72;    // u64 address of the next block
 constexpr int OFF_PL = 80;
@@ -163,10 +175,17 @@ constexpr int OFF_REM = (E_HOME + (REM_LISTS ? NUM_ENT : 0) + 3) & ~3;   // REM_
 constexpr int OFF_WORLD = (OFF_REM + REM_LISTS * REM_LIST_BYTES + 3) & ~3;   // WORLD_CAP x WORLD_BYTES
 // extended-record scalars: X_CTX the world the engine is currently acting in; X_RNGBLK index of the record's current
 // stream block (0 = first 624 outputs); X_SEED the game's seed (a world's old stream position may need a block that
-// is no longer resident); X_USED_HI entity slots 32..127 of H_USED (three more words)
+// is no longer resident); X_USED_HI entity slots 32.. of H_USED (USED_WORDS - 1 more words); X_TRIGSRC the has_source
+// bits of the trigger stack where a slot id needs all eight bits of its entry (TRIG_WIDE)
+constexpr int USED_WORDS = (NUM_ENT + 31) / 32;
+constexpr bool TRIG_WIDE = NUM_ENT > 128;
+constexpr int TRIG_SLOT = TRIG_WIDE ? 0xff : 0x7f;   // the slot bits of a trigger-stack entry
 constexpr int OFF_X = OFF_WORLD + WORLD_CAP * WORLD_BYTES;
 constexpr int X_CTX = OFF_X, X_RNGBLK = OFF_X + 2, X_SEED = OFF_X + 4, X_USED_HI = OFF_X + 8;
-constexpr int STATE_BYTES = (OFF_X + (REM_LISTS ? 20 : 0) + 15) & ~15;   // whole 16-byte granules
+constexpr int X_TRIGSRC = X_USED_HI + 4 * (USED_WORDS - 1);
+constexpr int X_BYTES = REM_LISTS ? (X_TRIGSRC - OFF_X) + (TRIG_WIDE ? 4 : 0) : 0;
+constexpr int STATE_BYTES = (OFF_X + X_BYTES + 15) & ~15;   // whole 16-byte granules
+static_assert(NUM_ENT <= 254 && (!TRIG_WIDE || REM_LISTS), "slot ids are bytes; 0xFE and 0xFF are markers");
 constexpr int STATE_WORDS = STATE_BYTES / 4;
 constexpr int EF_OWNER = 1, EF_FF = 2, EF_RESOLVING_PLAY = 4, EF_SINGLE_USE = 8;
 typedef uint32_t msb_u32x4 __attribute__((vector_size(16)));

@@ -13,7 +13,8 @@ def _ptr(a):
 
 class BatchEngine:
     def __init__(self, max_games, device=0, lanes_per_game=0, stack_bytes=0, extended=False):
-        """extended=True loads the build with the larger per-game record (decks holding ua20 / b005).
+        """extended=True loads the build with the larger per-game record (decks holding ua20 / b005), extended=2 the
+        one with the largest (254 entity slots; the replay tier of monsoon_amd/fitness.py).
         lanes_per_game selects a hot-kernel variant of the build (0 = default); a value the build does not hold is
         refused."""
         self.lib = _lib.load(extended)
@@ -213,6 +214,12 @@ class BatchEngine:
         # the handle now holds the last batch of the schedule
         self.n = len(m) - ((len(m) - 1) // self.max_games) * self.max_games
         return (counts, results, steps) if want_results else counts
+
+    def rollout_faults(self, n_matches):
+        """Fault code of every game of the last rollout (>= 16: a limit of this build's record, see include/monsoon.h)."""
+        out = np.zeros(n_matches, dtype=np.uint8)
+        self._ck(self.lib.monsoon_rollout_faults(self.h, _ptr(out), n_matches), "monsoon_rollout_faults")
+        return out
 
     # ---- device-resident rounds (bench) -------------------------------------------------------
     def upload_weights(self, weights):

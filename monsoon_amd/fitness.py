@@ -79,6 +79,27 @@ def fitness_from_counts(counts, games_per_individual):
     return [float((counts[i, 0] + 0.5 * counts[i, 1]) / games_per_individual) for i in range(len(counts))]
 
 
+CAPACITY_CODE = 16   # fault codes >= this are limits of a build's record (csrc/msb_base.h), not reference behaviour
+
+
+def replace_capacity_faulted(counts, results, steps, faults, matches, replay):
+    """The games of a rollout that hit a limit of the record (fault code >= 16: the reference's deep copies nest without
+    bound, a record does not) are played again by `replay(sub_matches) -> (counts, results, steps, faults)` -- the same
+    games on the build with the larger record -- and the rows of the first attempt replaced.  Returns the number of
+    games replayed; the arrays are updated in place."""
+    bad = np.nonzero(faults >= CAPACITY_CODE)[0]
+    if len(bad) == 0:
+        return 0
+    c2, r2, s2, f2 = replay(matches[bad])
+    p1 = matches["p1"][bad]
+    np.subtract.at(counts[:, 0], p1, results[bad] == 0)
+    np.subtract.at(counts[:, 1], p1, results[bad] == -1)
+    np.subtract.at(counts[:, 2], p1, 1)
+    counts += np.asarray(c2, dtype=counts.dtype)
+    results[bad], steps[bad], faults[bad] = r2, s2, f2
+    return len(bad)
+
+
 class FitnessEvaluator:
     def __init__(self, config, deck_config=None, rollout_fn=None, device=None):
         self.config = config
@@ -92,23 +113,40 @@ class FitnessEvaluator:
         self._rollout_fn = rollout_fn
         self._device = device
         self._engines = {}
+        self.capacity_replays = 0       # games replayed on the large record
+        self.capacity_faults = 0        # games not even the large record could hold (their fault code ends them as draws)
 
     # -- device ------------------------------------------------------------------------------
     def _hip_rollout(self, weights, matches, deck_pairs, max_turns):
         from .cards import needs_extended
         from .engine import BatchEngine
-        ext = bool(needs_extended(deck_pairs))   # ua20 / b005 only run on the extended-record build
-        if self._engines.get(ext) is None:
-            dev = self._device
-            if dev is None:
-                import os
-                dev = int(os.environ.get("LOCAL_RANK", "0"))
-            self._engines[ext] = BatchEngine(self.config.max_concurrent_games, device=dev, lanes_per_game=self.config.lanes_per_game,
-                                             extended=ext)
-        eng = self._engines[ext]
-        before = eng.stats()["lookahead_steps"]
-        counts = eng.rollout(weights, matches, deck_pairs, max_turns)
-        self.total_env_steps += eng.stats()["lookahead_steps"] - before
+        ext = int(bool(needs_extended(deck_pairs)))   # ua20 / b005 only run on the extended-record build
+
+        def engine(tier):
+            if self._engines.get(tier) is None:
+                dev = self._device
+                if dev is None:
+                    import os
+                    dev = int(os.environ.get("LOCAL_RANK", "0"))
+                # the large record is a replay tier for a few games per thousand: a small handle, its default variant
+                games = self.config.max_concurrent_games if tier < 2 else min(self.config.max_concurrent_games, 2048)
+                self._engines[tier] = BatchEngine(games, device=dev, lanes_per_game=self.config.lanes_per_game if tier < 2 else 0, extended=tier)
+            return self._engines[tier]
+
+        def play(tier, sub):
+            eng = engine(tier)
+            before = eng.stats()["lookahead_steps"]
+            counts, results, steps = eng.rollout(weights, sub, deck_pairs, max_turns, want_results=True)
+            self.total_env_steps += eng.stats()["lookahead_steps"] - before
+            return counts.astype(np.int64), results, steps, eng.rollout_faults(len(sub))
+
+        counts, results, steps, faults = play(ext, matches)
+        if ext:
+            # nested b005 memories are deep copies of the whole game (cards/b005.py:14-33, card.py:71-75): the few games
+            # whose copies outgrow the extended record (128 entity slots) are replayed on the large one (254)
+            self.capacity_replays += replace_capacity_faulted(counts, results, steps, faults, matches, lambda sub: play(2, sub))
+        self.capacity_faults += int((faults >= CAPACITY_CODE).sum())
+        self.last_rollout = (results, steps, faults)
         return counts
 
     def _decks_for(self, matches, generation):
@@ -201,7 +239,7 @@ class FitnessEvaluator:
         return {"total_games": self.total_games, "total_time": self.total_time,
                 "avg_time_per_game": self.total_time / max(self.total_games, 1),
                 "games_per_second": self.total_games / max(self.total_time, 1e-6),
-                "env_steps": self.total_env_steps,
+                "env_steps": self.total_env_steps, "capacity_replays": self.capacity_replays, "capacity_faults": self.capacity_faults,
                 "env_steps_per_second": self.total_env_steps / max(self.total_time, 1e-6)}
 
     def reset_stats(self):

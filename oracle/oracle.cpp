@@ -34,6 +34,7 @@ struct Game {
   int result;     // -2 running, -1 draw, 0 P1 win, 1 P2 win
   int steps;      // committed decisions
   uint64_t lookahead_steps;
+  int la_fault;   // first capacity code (>= FAULT_CAPACITY) a look-ahead step of this game hit (the product's GameMeta.la_fault)
 };
 
 struct Oracle {
@@ -107,6 +108,7 @@ int decide(Game& g, const double* w, double* scores_out, int* n_legal_out, uint6
     ce.step(a);
     g.lookahead_steps++;
     double s = 0.0;  // except Exception -> 0.0 (evo/heuristic_agent.py:48-51)
+    if (ce.fault() >= FAULT_CAPACITY && !g.la_fault) g.la_fault = ce.fault();
     if (!ce.fault() && !before_raises && !ce.observation_raises()) {
       double fa[10];
       ce.features(fa);
@@ -173,6 +175,7 @@ int orc_reset(void* h, int gi, uint32_t seed, const uint8_t* deck0, const uint8_
   g.result = -2;
   g.steps = 0;
   g.lookahead_steps = 0;
+  g.la_fault = 0;
   Engine<FlatMem> e = engine(g);
   e.init_game(deck0, deck1, f0, f1, seed);
   commit_rng(g, e);
@@ -264,6 +267,12 @@ void orc_usage(void* h, int gi, int* out) {
   for (int w = 1; w <= WORLD_CAP; w++) out[2] += g.st[OFF_WORLD + (w - 1) * WORLD_BYTES + W_USED] ? 1 : 0;
 }
 
+// monsoon_game_faults of the product: the fault that stopped the game, else the first capacity code a look-ahead hit
+int orc_game_fault(void* h, int gi) {
+  Game& g = ((Oracle*)h)->games[gi];
+  return g.st[H_FAULT] ? g.st[H_FAULT] : g.la_fault;
+}
+
 // scores156: NaN for illegal actions.  Returns the chosen action.
 void orc_lookahead_faults(void* h, int gi, uint8_t* out156) { lookahead_faults(((Oracle*)h)->games[gi], out156); }
 
@@ -333,6 +342,7 @@ int orc_scn_build(void* h, int gi, uint32_t seed, uint32_t stream_pos, const int
   g.result = -2;
   g.steps = 0;
   g.lookahead_steps = 0;
+  g.la_fault = 0;
   memset(g.st, 0, sizeof(g.st));
   uint32_t blocks = stream_pos / MT_N;
   for (uint32_t b = 0; b < blocks; b++) {

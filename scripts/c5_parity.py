@@ -39,4 +39,31 @@ bad = int((results != ores).sum() + (steps != osteps).sum() + (hashes != ohash).
 codes, cnt = np.unique(faults, return_counts=True)
 print(f"{n} random-deck games: GPU rollout {t1 - t0:.2f} s, CPU replay (16 threads) {t3 - t2:.2f} s, {total / 1e6:.1f} M env-steps, "
       f"mismatching games {bad}, fault codes {dict(zip(codes.tolist(), cnt.tolist()))}")
-sys.exit(1 if bad else 0)
+# the replay tier of monsoon_amd/fitness.py: games the extended record cannot hold, again on the large record -- and the
+# same on the CPU replay
+from monsoon_amd.fitness import replace_capacity_faulted  # noqa: E402
+from oracle_rollout import oracle_rollout_tier  # noqa: E402
+counts = np.zeros((1, 3), dtype=np.int64)
+counts[0] = [(results == 0).sum(), (results == -1).sum(), n]
+rf = eng.rollout_faults(n)
+assert np.array_equal(rf, faults)
+big = BatchEngine(2048, extended=2)
+
+
+def replay_hip(sub):
+    c, r, s = big.rollout(W0[None], sub, pairs, 200, want_results=True)
+    return c.astype(np.int64), r, s, big.rollout_faults(len(sub))
+
+
+t4 = time.time()
+k = replace_capacity_faulted(counts, results, steps, rf, m, replay_hip)
+t5 = time.time()
+ocounts = np.zeros((1, 3), dtype=np.int64)
+ocounts[0] = [(ores == 0).sum(), (ores == -1).sum(), n]
+of = np.array([orc.game_fault(g) for g in range(n)], dtype=np.uint8)
+replace_capacity_faulted(ocounts, ores, osteps, of, m, lambda sub: oracle_rollout_tier(W0[None], sub, pairs, 200, 2))
+bad2 = int((results != ores).sum() + (steps != osteps).sum() + (rf != of).sum() + (counts != ocounts).sum())
+codes, cnt = np.unique(rf, return_counts=True)
+print(f"replay tier: {k} games replayed on the large record in {t5 - t4:.2f} s, mismatching games {bad2}, "
+      f"fault codes after replay {dict(zip(codes.tolist(), cnt.tolist()))}")
+sys.exit(1 if bad or bad2 else 0)

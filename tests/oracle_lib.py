@@ -12,6 +12,7 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ORACLE_DIR = os.path.join(REPO, "oracle")
 LIB_PATH = os.path.join(ORACLE_DIR, "liboracle.so")
 LIB_PATH_EXT = os.path.join(ORACLE_DIR, "liboracle_ext.so")   # extended record (ua20, b005)
+LIB_PATH_BIG = os.path.join(ORACLE_DIR, "liboracle_big.so")   # large extended record (extended=2)
 
 
 def build():
@@ -23,7 +24,7 @@ _libs = {}
 
 def lib(extended=False):
     if extended not in _libs:
-        path = LIB_PATH_EXT if extended else LIB_PATH
+        path = extended if isinstance(extended, str) else (LIB_PATH, LIB_PATH_EXT, LIB_PATH_BIG)[int(extended)]
         if not os.path.exists(path):
             build()
         L = ctypes.CDLL(path)
@@ -46,6 +47,7 @@ def lib(extended=False):
         L.orc_decide.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
         L.orc_lookahead_faults.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
         L.orc_lookahead_faults.restype = None
+        L.orc_game_fault.argtypes = [ctypes.c_void_p, ctypes.c_int]
         L.orc_rollout.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p,
                                   ctypes.c_void_p, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_uint64),
                                   ctypes.POINTER(ctypes.c_int)]
@@ -179,6 +181,10 @@ class Oracle:
             out["actions"] = acts[:ns.value]
             out["hashes"] = hashes[:ns.value]
         return out
+
+    def game_fault(self, i):
+        """monsoon_game_faults of the product: the fault that stopped game i, else the first capacity code a look-ahead hit."""
+        return int(self.L.orc_game_fault(self.h, i))
 
     def rollout_batch(self, n, w, max_turns, threads):
         """Rollouts of games [0, n) (same weights both sides) on `threads` host threads."""

@@ -494,6 +494,61 @@ def test_random_deck_rollouts_extended_build_bit_exact(engines):
     assert (faults == 1).sum() > n // 10 and (faults == 20).sum() == 0 and (faults >= 16).sum() <= n // 200
 
 
+from c5_games import C5_OVERFLOWING, c5_games as _c5_games  # noqa: E402
+
+
+def test_large_record_build_matches_its_replay(engines):
+    """libmonsoon_hip_big.so (254 entity slots, 32 memory lists, 16 worlds): rollouts of C5 games -- the ones that overflow
+    the extended record and 108 ordinary ones -- equal the CPU replay on the same record: results, decisions, fault codes,
+    final canonical records.  On the games the extended record CAN hold, the three quantities also equal the extended
+    build's: the record layout is not observable."""
+    idx = C5_OVERFLOWING + list(range(108))
+    m, pairs = _c5_games(idx)
+    n = len(idx)
+    big = engines(n, extended=2)
+    assert big.lib.monsoon_version() & 0x20000
+    _, results, steps = big.rollout(W0[None], m, pairs, 200, want_results=True)
+    hashes, faults = big.state_hash(), big.rollout_faults(n)
+    assert np.array_equal(faults, big.game_faults())
+    orc = oracle_lib.Oracle(n, extended=2)
+    for g in range(n):
+        assert orc.reset(g, int(m["seed"][g]), pairs[g, 0], pairs[g, 1]) == 0
+    _, ores, osteps, ohash = orc.rollout_batch(n, W0, 200, 16)
+    assert np.array_equal(results, ores) and np.array_equal(steps, osteps) and np.array_equal(hashes, ohash)
+    assert np.array_equal(faults, [orc.game_fault(g) for g in range(n)])
+    assert (faults[:len(C5_OVERFLOWING)] >= 16).sum() <= 4    # what not even 254 slots hold (2063, 6149, 10993 here)
+    ext = engines(n, extended=True)
+    _, r1, s1 = ext.rollout(W0[None], m, pairs, 200, want_results=True)
+    f1, h1 = ext.rollout_faults(n), ext.state_hash()
+    fits = f1 < 16
+    assert (~fits).sum() >= len(C5_OVERFLOWING) - 1 and fits[len(C5_OVERFLOWING):].all()
+    assert np.array_equal(r1[fits], results[fits]) and np.array_equal(s1[fits], steps[fits]) and np.array_equal(h1[fits], hashes[fits])
+    assert np.array_equal(f1[fits], faults[fits])
+
+
+def test_fitness_rollout_replays_overflowing_games_on_the_large_record():
+    """FitnessEvaluator's rollout (Seam F): the games the extended record cannot hold are replayed on the large record and
+    their rows replaced -- counts, results, decision counts and fault codes equal the CPU replay doing the same."""
+    from oracle_rollout import oracle_rollout_fn_mt
+    from monsoon_amd.config import EvolutionaryConfig
+    from monsoon_amd.fitness import FitnessEvaluator
+    idx = C5_OVERFLOWING + list(range(300, 492))
+    m, pairs = _c5_games(idx)
+    rs = np.random.RandomState(12)
+    weights = rs.uniform(0, 1, (8, 10))
+    weights[0] = W0
+    m["p1"], m["p2"] = rs.randint(0, 8, len(idx)), rs.randint(0, 8, len(idx))
+    m["p1"][:len(C5_OVERFLOWING)] = m["p2"][:len(C5_OVERFLOWING)] = 0    # W0 on both sides: the games known to overflow
+    fe = FitnessEvaluator(EvolutionaryConfig(max_concurrent_games=128, max_turns=200))   # two batches on the extended build
+    counts = fe._hip_rollout(weights, m, pairs, 200)
+    results, steps, faults = fe.last_rollout
+    ocounts, ores, osteps, ofaults = oracle_rollout_fn_mt(weights, m, pairs, 200, want_faults=True)
+    assert np.array_equal(counts, ocounts) and counts[:, 2].sum() == len(idx)
+    assert np.array_equal(results, ores) and np.array_equal(steps, osteps) and np.array_equal(faults, ofaults)
+    st = fe.get_stats()
+    assert st["capacity_replays"] >= len(C5_OVERFLOWING) - 1 and st["capacity_faults"] == int((ofaults >= 16).sum()) <= 4
+
+
 def test_config_c3_ga_loop_through_the_hip_path(tmp_path):
     """BASELINE configs[2] (C3): the GA driver loop of evo/evolution.py:60-111 -- mu = lambda = 128, 64 games per
     individual (ring schedule), N12M, seed 42 -- for two generations (8 192 + 16 384 games, 200 decisions each) through

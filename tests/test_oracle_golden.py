@@ -249,3 +249,25 @@ def test_reference_unit_tests_as_scenarios(oracle_mod):
             n_calls += 1
         n_tests += 1
     assert n_tests == 113 + 7 and n_calls > 550 and orders > 150   # + the quirk scenarios of SURVEY §0 (G6)
+
+
+def test_replay_tier_for_games_the_extended_record_cannot_hold():
+    """Nested b005 memories are deep copies of the whole game; a record is finite.  The games whose copies outgrow the
+    extended record (fault code >= 16) are replayed on the large record (monsoon_amd/fitness.py::replace_capacity_faulted,
+    mirrored by tests/oracle_rollout.py): their rows then equal a direct run on the large record, every other row is
+    untouched, and on games both records hold the two builds agree."""
+    from c5_games import C5_OVERFLOWING, c5_games
+    from oracle_rollout import oracle_rollout_fn, oracle_rollout_tier
+    idx = C5_OVERFLOWING[:10] + list(range(10))
+    m, pairs = c5_games(idx)
+    w = np.random.RandomState(2024).uniform(0, 1, 10)[None]   # W0 of tests/test_gpu_parity.py, under which the list was drawn up
+    c1, r1, s1, f1 = oracle_rollout_tier(w, m, pairs, 200, 1)
+    c2, r2, s2, f2 = oracle_rollout_tier(w, m, pairs, 200, 2)
+    ct, rt, st, ft = oracle_rollout_fn(w, m, pairs, 200, want_faults=True)
+    over = f1 >= 16
+    assert over[:10].sum() >= 9 and not over[10:].any()
+    assert np.array_equal(rt[over], r2[over]) and np.array_equal(st[over], s2[over]) and np.array_equal(ft[over], f2[over])
+    assert np.array_equal(rt[~over], r1[~over]) and np.array_equal(st[~over], s1[~over]) and np.array_equal(ft[~over], f1[~over])
+    assert np.array_equal(r1[~over], r2[~over]) and np.array_equal(s1[~over], s2[~over])
+    assert (ft >= 16).sum() < over.sum() and (ft >= 16).sum() <= 2       # 2063 does not fit 254 slots either
+    assert ct[0, 2] == len(idx) and ct[0, 0] == (rt == 0).sum() and ct[0, 1] == (rt == -1).sum()
