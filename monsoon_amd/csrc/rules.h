@@ -842,12 +842,13 @@ struct Engine {
   // live world's board or trigger stack.  Returns the set of live entity slots.
   MSB_HD MSB_NOINLINE Bits rem_collect(Bits used) {
     Bits todo = used;
-    uint32_t lists = 0, worlds = 0;
+    uint64_t lists = 0;
+    uint32_t worlds = 0;
     while (todo.any()) {
       const int e = todo.pop();
       const int L = m.ld8(E_REM + e);
-      if (L != REM_NONE && L < REM_LISTS && !((lists >> L) & 1u)) {
-        lists |= 1u << L;
+      if (L != REM_NONE && L < REM_LISTS && !((lists >> L) & 1ull)) {
+        lists |= 1ull << L;
         int n = rem_n(L);
         for (int k = 0; k < n; k++) {
           int r = rem_get(L, k);
@@ -873,7 +874,7 @@ struct Engine {
         }
       }
     }
-    for (int l = 0; l < REM_LISTS; l++) m.st8(rem_off(l) + 1, (lists >> l) & 1u);
+    for (int l = 0; l < REM_LISTS; l++) m.st8(rem_off(l) + 1, (int)((lists >> l) & 1ull));
     for (int w = 1; w <= WORLD_CAP; w++) m.st8(world_off(w) + W_USED, (worlds >> w) & 1u);
     return used;
   }
@@ -887,31 +888,32 @@ struct Engine {
     m.st8(E_HOME + c, m.ld8(E_HOME + h) & 0x7f);
     return c;
   }
-  // deepcopy of world src as it is now (only called while the record holds the real game, ctx 0).  The entity the
+  // deepcopy of world src as it is now (from any context: a restored b005 remembers inside its own world).  The entity the
   // running deepcopy started from keeps its identity inside the snapshot: where src's board holds root_old the
   // snapshot holds root_new (deepcopy's memo).
   MSB_HD MSB_NOINLINE int world_snapshot(int src, int root_old, int root_new) {
-    if (ctx() != 0) {
-      set_fault(FAULT_UNSUPPORTED);
-      return 0;
-    }
     if (src == WORLD_LOST) return WORLD_LOST;
     const int w = world_alloc();
     if (w == WORLD_LOST) return w;
-    const int o = world_off(w), so = src ? world_off(src) : 0;
-    m.st8(o + W_PARTIAL, src ? m.ld8(so + W_PARTIAL) : 0);
-    m.st8(o + W_TOPLAY, src ? m.ld8(so + W_TOPLAY) : m.ld8(H_TOPLAY));
-    m.st8(o + W_RESOLVING, src ? m.ld8(so + W_RESOLVING) : m.ld8(H_RESOLVING));
-    m.st8(o + W_PHASE, src ? m.ld8(so + W_PHASE) : m.ld8(H_PHASE));
-    m.st8(o + W_CP, src ? m.ld8(so + W_CP) : m.ld8(H_CP));
+    // Where world src's swapped fields are right now (swap_world): in the record's own fields if the engine is acting
+    // in it ("live"), else in a storage slot -- its own, or, for the real game while ctx = c != 0, slot c.  W_PARTIAL
+    // and W_RNG never move: they stay in the world's own slot (the real game: never partial, the record's cursor).
+    const int c = ctx();
+    const bool live = src == c;
+    const int o = world_off(w), so = live ? 0 : world_off(src ? src : c);
+    m.st8(o + W_PARTIAL, src ? m.ld8(world_off(src) + W_PARTIAL) : 0);
+    m.st8(o + W_TOPLAY, !live ? m.ld8(so + W_TOPLAY) : m.ld8(H_TOPLAY));
+    m.st8(o + W_RESOLVING, !live ? m.ld8(so + W_RESOLVING) : m.ld8(H_RESOLVING));
+    m.st8(o + W_PHASE, !live ? m.ld8(so + W_PHASE) : m.ld8(H_PHASE));
+    m.st8(o + W_CP, !live ? m.ld8(so + W_CP) : m.ld8(H_CP));
     for (int p = 0; p < 2; p++) {
-      m.st8(o + W_FRONT + p, src ? m.ld8(so + W_FRONT + p) : m.ld8(pl(p, P_FRONT)));
-      m.st16(o + W_BASE + 2 * p, src ? m.ld16(so + W_BASE + 2 * p) : m.ld16(pl(p, P_BASE)));
+      m.st8(o + W_FRONT + p, !live ? m.ld8(so + W_FRONT + p) : m.ld8(pl(p, P_FRONT)));
+      m.st16(o + W_BASE + 2 * p, !live ? m.ld16(so + W_BASE + 2 * p) : m.ld16(pl(p, P_BASE)));
     }
-    m.st32(o + W_RNG, src ? m.ld32(so + W_RNG)
+    m.st32(o + W_RNG, src ? m.ld32(world_off(src) + W_RNG)
                           : ((uint32_t)m.ld16(X_RNGBLK) & 0xffffu) * (uint32_t)MT_N + ((uint32_t)m.ld16(H_RNGPOS) & 0xffffu));
     for (int t = 0; t < 20; t++) {
-      int h = src ? m.ld8(so + W_BOARD + t) : board_at(t);
+      int h = !live ? m.ld8(so + W_BOARD + t) : board_at(t);
       int nh = h;   // SLOT_NONE and SLOT_MISSING carry over
       if (h < NUM_ENT) {
         if (h == root_old) {
@@ -931,20 +933,20 @@ struct Engine {
       m.st8(o + W_BOARD + t, nh);
     }
     // pending triggers name entity objects: the copies standing on the same tiles (anything else is out of reach)
-    int tn = src ? m.ld8(so + W_TRIG_N) : m.ld8(H_TRIG_N);
+    int tn = !live ? m.ld8(so + W_TRIG_N) : m.ld8(H_TRIG_N);
     m.st8(o + W_TRIG_N, tn);
     for (int i = 0; i < tn; i++) {
-      int v = src ? m.ld8(so + W_TRIG + i) : m.ld8(OFF_TRIG + i);
+      int v = !live ? m.ld8(so + W_TRIG + i) : m.ld8(OFF_TRIG + i);
       int nv = -1;
       for (int t = 0; t < 20; t++)
-        if ((src ? m.ld8(so + W_BOARD + t) : board_at(t)) == (v & TRIG_SLOT)) nv = m.ld8(o + W_BOARD + t);
+        if ((!live ? m.ld8(so + W_BOARD + t) : board_at(t)) == (v & TRIG_SLOT)) nv = m.ld8(o + W_BOARD + t);
       if (nv < 0 || nv >= NUM_ENT) {
         m.st8(o + W_PARTIAL, 1);
         nv = 0;
       }
       m.st8(o + W_TRIG + i, nv | (TRIG_WIDE ? 0 : (v & 0x80)));
     }
-    if (TRIG_WIDE) m.st32(o + W_TRIGSRC, src ? m.ld32(so + W_TRIGSRC) : m.ld32(X_TRIGSRC));
+    if (TRIG_WIDE) m.st32(o + W_TRIGSRC, !live ? m.ld32(so + W_TRIGSRC) : m.ld32(X_TRIGSRC));
     return w;
   }
   // copy.deepcopy of a memory list (the list object, its entities, their own memories, and -- through entity.player

@@ -38,12 +38,12 @@ constexpr int DECK_CAP = 32;
 #if defined(MSB_CAP_REM)       // capacity studies (scripts/c5_capacity.py)
 constexpr int REM_LISTS = MSB_CAP_REM, WORLD_CAP = MSB_CAP_WORLD;
 #elif MSB_EXT == 2             // the LARGE record: where monsoon_rollout replays the games the extended record cannot hold
-constexpr int REM_LISTS = 32, WORLD_CAP = 16;
+constexpr int REM_LISTS = 64, WORLD_CAP = 16;
 #else
 constexpr int REM_LISTS = 16;  // memory lists (one per b005 with a pending memory, nested ones included)
 constexpr int WORLD_CAP = 8;   // frozen world snapshots alive at once (see below)
 #endif
-static_assert(REM_LISTS <= 32 && WORLD_CAP < 32, "rem_collect keeps the live lists and worlds in 32-bit sets");
+static_assert(REM_LISTS <= 64 && WORLD_CAP < 32, "rem_collect keeps the live lists in a 64-bit and the live worlds in a 32-bit set");
 #else
 constexpr int DECK_CAP = 12;
 constexpr int REM_LISTS = 0;

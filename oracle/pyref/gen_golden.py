@@ -348,6 +348,40 @@ def gen_heuristic_pool(n_games, max_turns, jobs, seed0=700, ext=False):
           "ended by an exception", int(np.sum(out["fault"])))
 
 
+def gen_heuristic_c5(indices, max_turns, jobs):
+    """Heuristic self-play of chosen games of the C5 family (tests/c5_games.py: seed 90000 + k, decks drawn by
+    RandomState(k ^ 0x9E3779B9) from the 109 observable cards): games whose nested b005 memories outgrow the product's
+    extended record -- the product replays them on its large record (libmonsoon_hip_big.so) and must reproduce these."""
+    pool = [c for c in H.CARD_IDS if c not in ("up01", "up02", "up03")]
+    tasks, decks = [], []
+    for k in indices:
+        rs = np.random.RandomState(k ^ 0x9E3779B9)
+        d0 = [str(c) for c in rs.choice(pool, 12, replace=False)]
+        d1 = [str(c) for c in rs.choice(pool, 12, replace=False)]
+        tasks.append((90000 + k, d0, d1, max_turns))
+        decks.append([idx(d0), idx(d1)])
+    with ProcessPoolExecutor(jobs) as ex:
+        results = list(ex.map(heuristic_trace, tasks))
+    out = dict(seeds=[], offsets=[0], result=[], fault=[], action=[], hash=[], best=[], shash=[], nlegal=[])
+    for seed, rec, result, fault in results:
+        out["seeds"].append(seed)
+        out["result"].append(result)
+        out["fault"].append(fault)
+        for k in ("action", "hash", "best", "shash", "nlegal"):
+            out[k] += rec[k]
+        out["offsets"].append(len(out["action"]))
+    np.savez_compressed(
+        os.path.join(GOLD, "trace_heuristic_c5_big.npz"), seeds=np.array(out["seeds"], dtype=np.uint32),
+        offsets=np.array(out["offsets"], dtype=np.int64), result=np.array(out["result"], dtype=np.int8),
+        fault=np.array(out["fault"], dtype=np.uint8),
+        action=np.array(out["action"], dtype=np.uint8), hash=np.array(out["hash"], dtype=np.uint64),
+        best=np.array(out["best"], dtype=np.float64), shash=np.array(out["shash"], dtype=np.uint64),
+        nlegal=np.array(out["nlegal"], dtype=np.int16), decks=np.array(decks, dtype=np.uint8), w0=W0, max_turns=np.int32(max_turns),
+        games=np.array(indices, dtype=np.int32))
+    print("trace_heuristic_c5_big.npz games", len(indices), "decisions", len(out["action"]), "look-ahead steps", int(np.sum(out["nlegal"])),
+          "ended by an exception", int(np.sum(out["fault"])))
+
+
 def gen_initial():
     recs, lens, seeds = [], [], []
     for deck in ("N12V", "N12M", "S12"):
@@ -438,6 +472,7 @@ def main():
         "heuristic_S12": lambda: gen_heuristic(16, 200, args.jobs, "S12", None, 300),
         "heuristic_pool": lambda: gen_heuristic_pool(24, 120, args.jobs),
         "heuristic_pool_ext": lambda: gen_heuristic_pool(16, 120, args.jobs, 900, ext=True),
+        "heuristic_c5_big": lambda: gen_heuristic_c5([264, 1374, 2103, 2458, 2649, 3525, 3540, 6149], 200, args.jobs),
         "heuristic_IRONCLAD": lambda: gen_heuristic(12, 120, args.jobs, "IRONCLAD", "SWARM", 400),
         "decks": gen_decks,
     }

@@ -111,7 +111,7 @@ def test_expert_bot_vs_reference(engines, gold):
 
 
 @pytest.mark.parametrize("fixture", ["trace_heuristic_N12M.npz", "trace_heuristic_S12.npz", "trace_heuristic_IRONCLAD.npz",
-                                     "trace_heuristic_pool.npz", "trace_heuristic_pool_ext.npz"])
+                                     "trace_heuristic_pool.npz", "trace_heuristic_pool_ext.npz", "trace_heuristic_c5_big.npz"])
 def test_heuristic_selfplay_vs_reference(engines, gold, fixture):
     """monsoon_decide against the reference's HeuristicAgent self-play (corrected loop): action,
     complete score vector, best score and committed state at every decision of the fixture's games (N12M mirror,
@@ -123,7 +123,8 @@ def test_heuristic_selfplay_vs_reference(engines, gold, fixture):
         decks = g["decks"]                       # a pair of 12-card decks per game
     else:
         decks = np.stack([g["deck"], g["deck1"] if "deck1" in g.files else g["deck"]])
-    ext = fixture.endswith("_ext.npz")
+    # "_big": games of the C5 family whose nested b005 memories outgrow the extended record, on the large record
+    ext = 2 if fixture.endswith("_big.npz") else fixture.endswith("_ext.npz")
     eng = engines(32, extended=ext)
     eng.reset(g["seeds"], decks)
     off = g["offsets"]

@@ -133,7 +133,13 @@ def test_set_iteration_order_known_answers(oracle_mod):
 
 
 HEURISTIC_FIXTURES = ["trace_heuristic_N12M.npz", "trace_heuristic_S12.npz", "trace_heuristic_IRONCLAD.npz", "trace_heuristic_pool.npz",
-                      "trace_heuristic_pool_ext.npz"]
+                      "trace_heuristic_pool_ext.npz", "trace_heuristic_c5_big.npz"]
+
+
+def _fixture_build(fixture):
+    """Which record a fixture's decks need: 0 standard, 1 extended (ua20 / b005), 2 large (games of the C5 family whose
+    nested b005 memories outgrow the extended record -- the product replays such games on libmonsoon_hip_big.so)."""
+    return 2 if fixture.endswith("_big.npz") else int(fixture.endswith("_ext.npz"))
 
 
 @pytest.mark.parametrize("fixture", HEURISTIC_FIXTURES)
@@ -144,7 +150,7 @@ def test_heuristic_selfplay_trace(oracle_mod, gold, fixture):
     look-aheads that raise (score 0.0) and committed steps that raise are common.  A game whose committed step raises
     in the reference (hash 0 in the fixture) must fault here at the same decision."""
     g = gold(fixture)
-    orc = oracle_mod.Oracle(1, extended=fixture.endswith("_ext.npz"))   # ua20 / b005 decks: extended record
+    orc = oracle_mod.Oracle(1, extended=_fixture_build(fixture))
     w = g["w0"]
     faults = g["fault"] if "fault" in g.files else np.zeros(len(g["seeds"]), dtype=np.uint8)
     for k, seed in enumerate(g["seeds"]):
