@@ -94,7 +94,7 @@ def load(extended=False):
         return _libs[extended]
     path = (LIB_PATH, LIB_PATH_EXT, LIB_PATH_BIG)[extended]
     if not extended and os.environ.get("MONSOON_LIB"):
-        path = os.environ["MONSOON_LIB"]   # development knob: A/B another build of the same ABI (scripts/ab_bench.sh)
+        path = os.environ["MONSOON_LIB"]   # development knob: A/B another build of the same ABI (scripts/ab_libs.sh)
     if not os.path.exists(path):
         raise MonsoonError(f"{path} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                            "or `make -C monsoon_amd/csrc all` (there is no CPU fallback)")

@@ -150,7 +150,7 @@ constexpr int MAX_DEPTH = MSB_CAP_DEPTH;   // capacity studies
 constexpr int MAX_DEPTH = 40;
 #endif
 
-// Which rules-core functions are inlined into their callers was settled by same-box A/B runs (scripts/ab_env.sh)
+// Which rules-core functions are inlined into their callers was settled by same-box A/B runs (scripts/ab_env.sh, scripts/ab_libs.sh)
 // measured (same-box A/B, 65 536 games): new_entity + set_path + calculate_front_line inlined +2.4 %;
 // entity_deal_damage inlined +0.6 %; player_play inlined -15 % in round 1's k_decide, +2 % in round 2's k_play (1 437-1 450 ->
 // 1 474 M env-steps/s; step_impl inlined as well: 1 462; to_next_turn inlined: 1 380; destroy inlined: 1 453)
@@ -432,6 +432,7 @@ struct Engine {
     m.st8(pl(o, (to_hand ? P_HAND : P_DECK) + n), id);
     rec = pl(o, P_INST + 4 * id);
     wrec = pl(o, P_AGE + id);
+    m.st8(pl(o, P_IPOS + id), IPOS_UNKNOWN);
 #else
     rec = pl(o, (to_hand ? P_HAND : P_DECK) + 4 * n);
     if (!to_hand) wrec = pl(o, P_AGE + n);
@@ -686,6 +687,9 @@ struct Engine {
           }
           m.st8(off + 2, (fl & ~CF_ALIAS) | CF_STR);
           m.st8(off + 3, str);
+#if defined(MSB_EXT) && MSB_EXT
+          m.st8(pl(o, P_IPOS + (off - pl(o, P_INST)) / 4), m.ld8g(eg(slot), EO_POS));   // ... and its last position
+#endif
         }
       }
     }
@@ -952,7 +956,7 @@ struct Engine {
   // copy.deepcopy of a memory list (the list object, its entities, their own memories, and -- through entity.player
   // -- the world each of them belongs to, once per deepcopy call: memo[])
   MSB_HD int rem_deep_copy(int src, int* memo, int root_old, int root_new, int depth) {
-    if (depth > 4) {
+    if (depth > REM_DEPTH) {
       set_fault(FAULT_CAP_REM);
       return REM_NONE;
     }
@@ -1774,6 +1778,15 @@ struct Engine {
   // (unit.py:25-26, structure.py:18-19); Spells compare identity (card.py:22-23).
   MSB_HD MSB_INL bool card_eq_by_id(int card) const { return card >= NUM_CARDS || g_cards[card].kind != KIND_SPELL; }
 
+#if defined(MSB_EXT) && MSB_EXT
+  // .position of a card object that has been on the board (b305 returns the structure OBJECT to the hand): the entity's
+  // recorded position while it is there, the one it had when it left afterwards
+  MSB_HD MSB_INL int inst_position(int o, int ref) const {
+    int fl = m.ld8(ref + 2), x = m.ld8(ref + 3);
+    if (fl & CF_ALIAS) return m.ld8g(eg(x), EO_POS);
+    return m.ld8(pl(o, P_IPOS + (ref - pl(o, P_INST)) / 4));
+  }
+#endif
   // list.remove(target): index of the first element EQUAL to the one at `idx`.  Unit/Structure
   // equality is (card_id, player, position); instances that came back from the board (b305) have a
   // position, fresh cards have None: comparing None with a Point raises (point.py:6-7).
@@ -1787,6 +1800,15 @@ struct Engine {
       if (!card_eq_by_id(card) || m.ld8(r) != card) continue;
       int pi = m.ld8(r + 2) & (CF_ALIAS | CF_STR);
       if (!pi && !positioned) return i;
+#if defined(MSB_EXT) && MSB_EXT
+      if (pi && positioned) {   // two objects that have both been on the board: equal iff their positions are
+        int pa = inst_position(o, r), pb = inst_position(o, tref);
+        if (pa != IPOS_UNKNOWN && pb != IPOS_UNKNOWN) {
+          if (pa == pb) return i;
+          continue;
+        }
+      }
+#endif
       set_fault((pi && positioned) ? FAULT_UNSUPPORTED : FAULT_PY_EXCEPTION);
       return idx;
     }

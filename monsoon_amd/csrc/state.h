@@ -57,6 +57,13 @@ constexpr int WORLD_CAP = 0;
 // Board.flip re-binds every on-board entity to the real players (board.py:108-115).  A world = board + trigger stack
 // + the scalar board/player fields an entity method can reach + its stream position; its entities are ordinary
 // entity slots whose E_HOME names the world.  Entity methods run "in the world of self.player" (rules.h ctx_*).
+#if defined(MSB_CAP_REMDEPTH)
+constexpr int REM_DEPTH = MSB_CAP_REMDEPTH;
+#elif defined(MSB_EXT) && MSB_EXT == 2
+constexpr int REM_DEPTH = 12;
+#else
+constexpr int REM_DEPTH = 4;      // memories inside remembered copies inside ... : levels one deepcopy follows
+#endif
 constexpr int REM_PER_LIST = 8;   // surrounding tiles
 constexpr int REM_LIST_BYTES = 4 + REM_PER_LIST;   // {n, used, pad2, REM_PER_LIST x entity slot}
 constexpr int REM_NONE = 0xFF;
@@ -125,7 +132,9 @@ constexpr int P_HAND = 12;                       // HAND_CAP x u8 instance id
 constexpr int P_DECK = P_HAND + HAND_CAP;        // DECK_CAP x u8 instance id
 constexpr int P_INST = (P_DECK + DECK_CAP + 3) & ~3;          // INST_CAP x {card, cost, flags, x}
 constexpr int P_AGE = P_INST + 4 * INST_CAP;                  // INST_CAP x u8 weight age (Card.weight = wtab[age], see below)
-constexpr int PL_SIZE = (P_AGE + INST_CAP + 15) & ~15;
+constexpr int P_IPOS = P_AGE + INST_CAP;                      // INST_CAP x u8: the .position a CF_STR object kept when it left the board
+constexpr int IPOS_UNKNOWN = 0xFF;                            //   (Structure.__eq__ compares it, structure.py:18-19)
+constexpr int PL_SIZE = (P_IPOS + INST_CAP + 15) & ~15;
 #else
 constexpr int P_HAND = 12;                      // HAND_CAP x {card, cost, flags, x}
 constexpr int P_DECK = P_HAND + 4 * HAND_CAP;   // DECK_CAP x {card, cost, flags, x}

@@ -21,6 +21,7 @@ by running it here and committing inputs + expected outputs (data only, no refer
 Usage: PYTHONHASHSEED=0 python oracle/pyref/gen_golden.py [--only NAME] [--jobs N]
 """
 import argparse
+import time
 import contextlib
 import io
 import os
@@ -360,8 +361,30 @@ def gen_heuristic_c5(indices, max_turns, jobs):
         d1 = [str(c) for c in rs.choice(pool, 12, replace=False)]
         tasks.append((90000 + k, d0, d1, max_turns))
         decks.append([idx(d0), idx(d1)])
-    with ProcessPoolExecutor(jobs) as ex:
-        results = list(ex.map(heuristic_trace, tasks))
+    # one process per game with a time limit: the reference's nested deep copies make a few of these games take hours
+    import multiprocessing as mp
+    limit = float(os.environ.get("C5_GAME_SECONDS", "600"))
+    ctx = mp.get_context("fork")
+    procs = []
+    for k, t in zip(indices, tasks):
+        q = ctx.Queue()
+        p = ctx.Process(target=lambda q=q, t=t: q.put(heuristic_trace(t)))
+        p.start()
+        procs.append((k, p, q))
+    results, kept, kept_decks = [], [], []
+    t_end = time.time() + limit
+    for (k, p, q), d in zip(procs, decks):
+        try:
+            r = q.get(timeout=max(1.0, t_end - time.time()))
+            results.append(r)
+            kept.append(k)
+            kept_decks.append(d)
+        except Exception:   # queue.Empty
+            print("game", k, "not finished by the reference within", limit, "s: left out")
+        p.join(timeout=1.0)
+        if p.is_alive():
+            p.terminate()
+    indices, decks = kept, kept_decks
     out = dict(seeds=[], offsets=[0], result=[], fault=[], action=[], hash=[], best=[], shash=[], nlegal=[])
     for seed, rec, result, fault in results:
         out["seeds"].append(seed)
@@ -472,7 +495,7 @@ def main():
         "heuristic_S12": lambda: gen_heuristic(16, 200, args.jobs, "S12", None, 300),
         "heuristic_pool": lambda: gen_heuristic_pool(24, 120, args.jobs),
         "heuristic_pool_ext": lambda: gen_heuristic_pool(16, 120, args.jobs, 900, ext=True),
-        "heuristic_c5_big": lambda: gen_heuristic_c5([264, 1374, 2103, 2458, 2649, 3525, 3540, 6149], 200, args.jobs),
+        "heuristic_c5_big": lambda: gen_heuristic_c5([264, 1374, 2103, 2458, 2649, 3525, 3540, 6149, 3691, 4215, 4593, 5070], 200, args.jobs),
         "heuristic_IRONCLAD": lambda: gen_heuristic(12, 120, args.jobs, "IRONCLAD", "SWARM", 400),
         "decks": gen_decks,
     }

@@ -33,13 +33,14 @@ def main():
     ap.add_argument("--ext", type=int, default=1)
     ap.add_argument("--ent", type=int, default=128)
     ap.add_argument("--depth", type=int, default=40)
+    ap.add_argument("--remdepth", type=int, default=4)
     ap.add_argument("--threads", type=int, default=8)
     args = ap.parse_args()
     d = os.path.join(REPO, "oracle", "_cap")
     os.makedirs(d, exist_ok=True)
     path = os.path.join(d, f"liboracle_{args.ext}_{args.ent}_{args.rem}_{args.world}.so")
     flags = "-O2 -std=c++17 -fPIC -ffp-contract=off -fno-strict-aliasing -fno-fast-math -Wno-psabi".split()
-    subprocess.run(["g++", *flags, f"-DMSB_EXT={args.ext}", f"-DMSB_CAP_REM={args.rem}", f"-DMSB_CAP_WORLD={args.world}", f"-DMSB_CAP_ENT={args.ent}", f"-DMSB_CAP_DEPTH={args.depth}", "-shared", "-o", path,
+    subprocess.run(["g++", *flags, f"-DMSB_EXT={args.ext}", f"-DMSB_CAP_REM={args.rem}", f"-DMSB_CAP_WORLD={args.world}", f"-DMSB_CAP_ENT={args.ent}", f"-DMSB_CAP_DEPTH={args.depth}", f"-DMSB_CAP_REMDEPTH={args.remdepth}", "-shared", "-o", path,
                     os.path.join(REPO, "oracle", "oracle.cpp"), "-lpthread"], check=True)
     pool = np.array([i for i, c in enumerate(CARD_IDS) if c not in ("up01", "up02", "up03")], dtype=np.uint8)
     n = args.games

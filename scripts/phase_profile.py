@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""k_decide phase timing (wave cycles per phase) with the profiling build libmonsoon_hip_prof.so.
+"""k_play phase timing (wave cycles per phase) with the profiling build libmonsoon_hip_prof.so.
 
     make -C monsoon_amd/csrc prof && gpurun -- python scripts/phase_profile.py [--games 65536]
 The profiling library is a diagnostics build of the same source (-DMSB_PROF=1); the package never loads it.
@@ -48,7 +48,7 @@ def main():
     ph = c[8:16].astype(np.float64)
     tot = ph.sum()
     kms, launches = eng.kernel_time()
-    print(f"games {n} decisions {dec} lookahead {look} ({look / max(dec, 1):.1f}/decision) k_decide {kms / max(launches, 1):.3f} ms/launch")
+    print(f"games {n} decisions {dec} lookahead {look} ({look / max(dec, 1):.1f}/decision) k_play {kms / max(launches, 1):.3f} ms/launch")
     print(f"wave cycles per decision: {tot / max(dec, 1):.0f}")
     for name, v in zip(PHASES, ph):
         print(f"  {name:24s} {v / max(dec, 1):10.0f} cycles/decision  {100 * v / tot:5.1f} %")

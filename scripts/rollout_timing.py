@@ -43,7 +43,7 @@ for rep in range(3):
     t3 = time.perf_counter()
     ms, launches = eng.kernel_time()
     st = eng.stats()
-    print(f"n={n} reset {1e3 * (t1 - t0):.1f} ms | rollout {1e3 * (t3 - t2):.1f} ms: k_decide {ms:.1f} ms in {launches} launches, "
+    print(f"n={n} reset {1e3 * (t1 - t0):.1f} ms | rollout {1e3 * (t3 - t2):.1f} ms: k_play {ms:.1f} ms in {launches} launches, "
           f"{st['lookahead_steps'] / 1e6:.1f} M env-steps, mean game length {steps.mean():.1f}, "
           f"{st['lookahead_steps'] / (t3 - t2) / 1e6:.0f} M env-steps/s, faults {st['faults']} (build limits {st['capacity_faults']}), "
           f"results P1/P2/draw {int((res == 0).sum())}/{int((res == 1).sum())}/{int((res == -1).sum())}", flush=True)
