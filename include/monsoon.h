@@ -186,7 +186,10 @@ int monsoon_get_stats(monsoon_t* h, monsoon_stats* out);
 int monsoon_reset_stats(monsoon_t* h);
 /* HIP-event timing of the decide kernel since the last reset_stats: total ms and launch count. */
 int monsoon_kernel_time(monsoon_t* h, double* total_ms, int64_t* launches);
-/* Raw stream handle (hipStream_t) so a caller can order its own work; NULL-safe. */
+/* The stream the handle launches on (hipStream_t) so a caller can order its own work; NULL-safe.  By default this is the
+ * device's default stream (returned as NULL) for every handle of every build: the kernels keep a per-lane stack in
+ * scratch memory, and two hardware queues that both hold scratch make the runtime move it between them at every launch
+ * (hundreds of ms).  MONSOON_OWN_STREAM=1 in the environment gives each handle a stream of its own again. */
 void* monsoon_stream(monsoon_t* h);
 
 #ifdef __cplusplus

@@ -433,6 +433,7 @@ struct monsoon {
   size_t counts_cap = 0;
   int8_t* d_results = nullptr;    // [matches_cap] results, then [matches_cap] fault codes (monsoon_rollout_faults)
   size_t rollout_matches = 0;     // matches of the last monsoon_rollout
+  bool own_stream = false;
   int32_t* d_steps = nullptr;
   size_t matches_cap = 0;
   // kernel timing: event pairs are created once and reused
@@ -525,7 +526,7 @@ void monsoon_destroy(monsoon_t* h) {
     hipEventDestroy(pr.first);
     hipEventDestroy(pr.second);
   }
-  if (h->stream) hipStreamDestroy(h->stream);
+  if (h->stream && h->own_stream) hipStreamDestroy(h->stream);
   delete h;
 }
 
@@ -535,7 +536,18 @@ static int create_impl(monsoon* h) {
   HIP_TRY(h, hipSetDevice(h->device));
   // the rules core recurses (move -> ability -> ...): give every lane a scratch stack
   HIP_TRY(h, hipDeviceSetLimit(hipLimitStackSize, (size_t)h->cfg.stack_bytes));
-  HIP_TRY(h, hipStreamCreate(&h->stream));
+  // Every handle of every build runs on the device's DEFAULT stream unless MONSOON_OWN_STREAM=1 asks for a stream per handle.
+  // The kernels need a per-lane stack (16-32 KiB x 64 lanes x resident waves = GBs of scratch per hardware queue); with two
+  // queues holding scratch (a standard and an extended handle alive, say) the runtime hands the scratch back and forth
+  // and EVERY k_play launch costs 200-500 ms instead of 0.2 ms (measured, scripts/probe/launch_cost2.py).  One queue, one
+  // scratch allocation: nothing to reclaim.
+  if (getenv("MONSOON_OWN_STREAM") && atoi(getenv("MONSOON_OWN_STREAM")) != 0) {
+    HIP_TRY(h, hipStreamCreate(&h->stream));
+    h->own_stream = true;
+  } else {
+    h->stream = nullptr;
+    h->own_stream = false;
+  }
   HIP_TRY(h, hipMalloc(&h->b.state, cap * SW * 4));
   HIP_TRY(h, hipMalloc(&h->b.rng_out, cap * RNG_WORDS * 4));
   HIP_TRY(h, hipMalloc(&h->b.rng_mt, cap * MT_N * 4));

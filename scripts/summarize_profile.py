@@ -25,11 +25,17 @@ src = sys.argv[2] if len(sys.argv) > 2 else f"gpurun_out/prof_{tag}"
 os.makedirs("profiles", exist_ok=True)
 args_file = os.path.join(src, "bench_args.txt")
 bench_args = open(args_file).read().strip() if os.path.exists(args_file) else "--steps 40 --warmup 20 --no-cpu"
-stats = glob.glob(f"{src}/trace/**/*_kernel_stats.csv", recursive=True)[0]
+def newest(pattern):
+    """gpurun merges every call's files into the same directory: take the most recent run's."""
+    files = sorted(glob.glob(pattern, recursive=True), key=os.path.getmtime)
+    return files[-1:] if files else []
+
+
+stats = newest(f"{src}/trace/**/*_kernel_stats.csv")[0]
 shutil.copy(stats, f"profiles/{tag}_kernel_stats.csv")
 means = {}
 for name in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_sq2"):
-    files = glob.glob(f"{src}/{name}/**/*_counter_collection.csv", recursive=True)
+    files = newest(f"{src}/{name}/**/*_counter_collection.csv")
     if not files:
         continue
     acc = collections.defaultdict(lambda: [0, 0.0])
@@ -45,7 +51,7 @@ for name in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_sq2"):
     means["_dispatch"] = meta
 kd = [r for r in csv.DictReader(open(stats)) if HOT(r["Name"])][0]
 # per-dispatch durations from the kernel trace: the last `launches` dispatches are bench.py's timed region
-trace_csv = glob.glob(f"{src}/trace/**/*_kernel_trace.csv", recursive=True)
+trace_csv = newest(f"{src}/trace/**/*_kernel_trace.csv")
 timed_avg_ns = None
 durs = []
 if trace_csv:
