@@ -21,8 +21,9 @@ import harness as H  # noqa: E402
 
 from evo.features import StateFeatures  # noqa: E402
 
-EXT = os.environ.get("MSB_EXT", "0") == "1"   # MSB_EXT=1: extended record (ua20, b005)
-LIB = ctypes.CDLL(os.path.join(H.REPO, "oracle", "liboracle_ext.so" if EXT else "liboracle.so"))
+BUILD = int(os.environ.get("MSB_EXT", "0"))   # MSB_EXT=1: extended record (ua20, b005); MSB_EXT=2: the large record
+EXT = BUILD >= 1
+LIB = ctypes.CDLL(os.path.join(H.REPO, "oracle", ("liboracle.so", "liboracle_ext.so", "liboracle_big.so")[BUILD]))
 LIB.orc_create.restype = ctypes.c_void_p
 LIB.orc_canon_hash.restype = ctypes.c_uint64
 for name in ("orc_reset", "orc_legal", "orc_step", "orc_observe", "orc_features", "orc_canon", "orc_destroy",
