@@ -511,6 +511,9 @@ def test_large_record_build_matches_its_replay(engines):
     _, results, steps = big.rollout(W0[None], m, pairs, 200, want_results=True)
     hashes, faults = big.state_hash(), big.rollout_faults(n)
     assert np.array_equal(faults, big.game_faults())
+    from monsoon_amd._lib import MonsoonError
+    with pytest.raises(MonsoonError):
+        big.rollout_faults(n + 1)   # not the size of the last rollout: refused, nothing copied
     orc = oracle_lib.Oracle(n, extended=2)
     for g in range(n):
         assert orc.reset(g, int(m["seed"][g]), pairs[g, 0], pairs[g, 1]) == 0
