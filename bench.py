@@ -73,9 +73,18 @@ def cpu_baseline(sample_games, max_turns, threads):
     t0 = time.perf_counter()
     total, _, steps, _ = orc.rollout_batch(sample_games, W0, max_turns, cores)
     dt = time.perf_counter() - t0
+    # "1 thread and all host cores" -- the same replay on one thread, a 32nd of the sample
+    one = max(64, sample_games // 32)
+    for i in range(one):
+        orc.reset(i, i, deck, deck)
+    t1 = time.perf_counter()
+    total1, _, _, _ = orc.rollout_batch(one, W0, max_turns, 1)
+    dt1 = time.perf_counter() - t1
     return {"value": total / dt, "unit": "env-steps/s", "cores": cores, "kind": "port",
             "sample": f"{sample_games} N12M self-play games to {max_turns} decisions ({total} look-ahead steps, "
                       f"{dt:.2f} s wall on {cores} threads)",
+            "one_thread": {"value": total1 / dt1, "unit": "env-steps/s", "cores": 1,
+                           "sample": f"{one} of those games ({total1} look-ahead steps, {dt1:.2f} s)"},
             "reference_python": REFERENCE_PYTHON}
 
 
