@@ -530,12 +530,12 @@ void monsoon_destroy(monsoon_t* h) {
   delete h;
 }
 
+static hipError_t bind_device(monsoon_t* h);
 static int create_impl(monsoon* h) {
   const monsoon_config& cfg = h->cfg;
   size_t cap = (size_t)cfg.max_games;
-  HIP_TRY(h, hipSetDevice(h->device));
-  // the rules core recurses (move -> ability -> ...): give every lane a scratch stack
-  HIP_TRY(h, hipDeviceSetLimit(hipLimitStackSize, (size_t)h->cfg.stack_bytes));
+  // the rules core recurses (move -> ability -> ...): every lane gets a scratch stack (device-wide limit, only ever raised)
+  HIP_TRY(h, bind_device(h));
   // Every handle of every build runs on the device's DEFAULT stream unless MONSOON_OWN_STREAM=1 asks for a stream per handle.
   // The kernels need a per-lane stack (16-32 KiB x 64 lanes x resident waves = GBs of scratch per hardware queue); with two
   // queues holding scratch (a standard and an extended handle alive, say) the runtime hands the scratch back and forth
@@ -613,11 +613,9 @@ int monsoon_create(const monsoon_config* cfg, monsoon_t** out) {
   memset(&h->b, 0, sizeof(h->b));
   h->cfg = *cfg;
   h->var = var;
-#if defined(MSB_EXT) && MSB_EXT
-  if (h->cfg.stack_bytes <= 0) h->cfg.stack_bytes = 32768;   // MAX_DEPTH 64 (rules.h)
-#else
-  if (h->cfg.stack_bytes <= 0) h->cfg.stack_bytes = 16384;
-#endif
+  // one default for every build (MAX_DEPTH 40 levels of the recursive rules core, rules.h): handles of different builds
+  // in one process then ask for the same device-wide limit.  Stack sizes from 4 to 48 KiB measure the same.
+  if (h->cfg.stack_bytes <= 0) h->cfg.stack_bytes = 32768;
   h->device = cfg->device;
   memset(h->st_acc, 0, sizeof(h->st_acc));
   memset(h->st_base, 0, sizeof(h->st_base));
@@ -638,15 +636,28 @@ int monsoon_variant(monsoon_t* h, int32_t* lanes_per_game, int32_t* waves_per_si
   return MONSOON_OK;
 }
 
+// Make the handle's device current and its per-lane stack available.  The stack limit is a DEVICE-wide setting: the last
+// handle created, of whatever build, would otherwise decide it for everybody, and a kernel of the recursive rules core
+// that runs with less stack than its build was given overruns it.  The limit is only ever raised (10 us when it happens).
+static hipError_t bind_device(monsoon_t* h) {
+  hipError_t e = hipSetDevice(h->device);
+  if (e != hipSuccess) return e;
+  size_t cur = 0;
+  e = hipDeviceGetLimit(&cur, hipLimitStackSize);
+  if (e != hipSuccess) return e;
+  if (cur < (size_t)h->cfg.stack_bytes) e = hipDeviceSetLimit(hipLimitStackSize, (size_t)h->cfg.stack_bytes);
+  return e;
+}
+
 static int check_ready(monsoon_t* h) {
   if (!h) return MONSOON_ERR_ARG;
   if (h->n <= 0) {
     h->err = "no games loaded: call monsoon_reset first";
     return MONSOON_ERR_STATE;
   }
-  hipError_t e = hipSetDevice(h->device);
+  hipError_t e = bind_device(h);
   if (e != hipSuccess) {
-    h->err = std::string("hipSetDevice: ") + hipGetErrorString(e);
+    h->err = std::string("hipSetDevice / stack limit: ") + hipGetErrorString(e);
     return MONSOON_ERR_DEVICE;
   }
   return MONSOON_OK;
@@ -678,7 +689,7 @@ int monsoon_reset(monsoon_t* h, int32_t n, const uint32_t* seeds, const uint8_t*
   }
   int rc = check_decks(h, decks, (size_t)n * 24, "monsoon_reset");
   if (rc) return rc;
-  HIP_TRY(h, hipSetDevice(h->device));
+  HIP_TRY(h, bind_device(h));
   rc = fold_stats(h);   // statistics live in the per-game rows that are about to be cleared
   if (rc) return rc;
   HIP_TRY(h, hipMemcpyAsync(h->d_seeds, seeds, (size_t)n * 4, hipMemcpyHostToDevice, h->stream));
@@ -868,7 +879,7 @@ int monsoon_state_load(monsoon_t* h, int32_t idx, const uint8_t* buf, int32_t bu
     h->err = "monsoon_state_load: not a state blob of this build, or slot out of range";
     return MONSOON_ERR_ARG;
   }
-  HIP_TRY(h, hipSetDevice(h->device));
+  HIP_TRY(h, bind_device(h));
   HIP_TRY(h, hipMemcpyAsync(h->d_bytes, buf, BLOB_BYTES, hipMemcpyHostToDevice, h->stream));
   hipLaunchKernelGGL(k_blob, dim3(1), dim3(256), 0, h->stream, h->b, idx, (uint32_t*)h->d_bytes, 1);
   HIP_TRY(h, hipGetLastError());
@@ -884,7 +895,7 @@ static int debug_call(monsoon_t* h, int32_t idx, int build, uint32_t seed, uint3
     if (h) h->err = "monsoon_debug_*: bad argument";
     return MONSOON_ERR_ARG;
   }
-  HIP_TRY(h, hipSetDevice(h->device));
+  HIP_TRY(h, bind_device(h));
   static_assert(3000 * 4 + (2 + 2 * DBG_TRACE_CAP) * 4 <= 16384, "staging buffer");
   int32_t* d_stream = (int32_t*)h->d_bytes;
   int32_t* d_out = d_stream + 3000;
@@ -924,7 +935,7 @@ int monsoon_debug_kat(monsoon_t* h, int32_t kind, uint32_t seed, int32_t n, cons
     if (h) h->err = "monsoon_debug_kat: bad argument";
     return MONSOON_ERR_ARG;
   }
-  HIP_TRY(h, hipSetDevice(h->device));
+  HIP_TRY(h, bind_device(h));
   const size_t in_bytes = kind == 2 ? (size_t)n * 4 : (kind == 4 ? (size_t)n * 240 : 0);
   const size_t out_bytes = kind == 3 ? (size_t)n * 48 : (kind == 1 || kind == 4 ? (size_t)n * 8 : (size_t)n * 4);
   void *d_in = nullptr, *d_out = nullptr;
@@ -980,7 +991,7 @@ int monsoon_state_hash(monsoon_t* h, uint64_t* out) {
 
 int monsoon_upload_weights(monsoon_t* h, const double* weights, int32_t n_individuals) {
   if (!h || !weights || n_individuals <= 0) return MONSOON_ERR_ARG;
-  HIP_TRY(h, hipSetDevice(h->device));
+  HIP_TRY(h, bind_device(h));
   if (n_individuals > h->weights_cap) {
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     if (h->b.weights) HIP_TRY(h, hipFree(h->b.weights));
@@ -1106,7 +1117,7 @@ int monsoon_play_rounds_dev(monsoon_t* h, int32_t rounds) {
 
 int monsoon_sync(monsoon_t* h) {
   if (!h) return MONSOON_ERR_ARG;
-  HIP_TRY(h, hipSetDevice(h->device));
+  HIP_TRY(h, bind_device(h));
   HIP_TRY(h, hipStreamSynchronize(h->stream));
   return drain_timing(h);
 }
@@ -1230,7 +1241,7 @@ int monsoon_rollout_faults(monsoon_t* h, uint8_t* out, int32_t n_matches) {
     h->err = "monsoon_rollout_faults: n_matches is not the size of the last completed monsoon_rollout";
     return MONSOON_ERR_ARG;
   }
-  HIP_TRY(h, hipSetDevice(h->device));
+  HIP_TRY(h, bind_device(h));
   HIP_TRY(h, hipMemcpy(out, (uint8_t*)h->d_results + h->matches_cap, (size_t)n_matches, hipMemcpyDeviceToHost));
   return MONSOON_OK;
 }
@@ -1269,7 +1280,7 @@ static int fold_stats(monsoon_t* h) {
 
 int monsoon_get_stats(monsoon_t* h, monsoon_stats* out) {
   if (!h || !out) return MONSOON_ERR_ARG;
-  HIP_TRY(h, hipSetDevice(h->device));
+  HIP_TRY(h, bind_device(h));
   unsigned long long s[ST_N];
   int rc = total_stats(h, s);
   if (rc) return rc;
@@ -1337,7 +1348,7 @@ int monsoon_debug_counters(monsoon_t* h, unsigned long long* out) {
 
 int monsoon_reset_stats(monsoon_t* h) {
   if (!h) return MONSOON_ERR_ARG;
-  HIP_TRY(h, hipSetDevice(h->device));
+  HIP_TRY(h, bind_device(h));
   HIP_TRY(h, hipStreamSynchronize(h->stream));
   drain_timing(h);
   {
@@ -1357,7 +1368,7 @@ int monsoon_reset_stats(monsoon_t* h) {
 
 int monsoon_kernel_time(monsoon_t* h, double* total_ms, int64_t* launches) {
   if (!h) return MONSOON_ERR_ARG;
-  HIP_TRY(h, hipSetDevice(h->device));
+  HIP_TRY(h, bind_device(h));
   HIP_TRY(h, hipStreamSynchronize(h->stream));
   int rc = drain_timing(h);
   if (rc) return rc;

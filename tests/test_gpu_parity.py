@@ -553,6 +553,39 @@ def test_fitness_rollout_replays_overflowing_games_on_the_large_record():
     assert st["capacity_replays"] >= len(C5_OVERFLOWING) - 1 and st["capacity_faults"] == int((ofaults >= 16).sum()) <= 4
 
 
+def test_handles_of_several_builds_alive_at_once():
+    """A standard, an extended and a large handle in one process (a deck schedule that mixes ua20 / b005 decks with plain
+    ones, the replay tier): they share one hardware queue and one device-wide stack limit.  With a stream per handle
+    every k_play launch cost 200-500 ms once two of them held scratch memory; a handle created later must
+    not shrink the stack of the kernels of an earlier one either.  Decisions stay bit-exact and launches stay cheap."""
+    import time
+    from monsoon_amd.engine import BatchEngine
+    deck = deck_indices("N12M")
+    engs = [BatchEngine(32, extended=t) for t in (1, 0, 2, 0)]   # the standard build is created AFTER the extended one
+    orcs = []
+    for e in engs:
+        e.reset(np.arange(32, dtype=np.uint32) + 7, np.stack([deck, deck]))
+        o = oracle_lib.Oracle(32, extended=e.extended)
+        for g in range(32):
+            o.reset(g, g + 7, deck, deck)
+        orcs.append(o)
+    t0 = time.time()
+    for _ in range(12):
+        for e, o in zip(engs, orcs):
+            action, _ = e.decide(W0)
+            hashes = e.state_hash()
+            for g in range(32):
+                a, _, _ = o.decide(g, W0)
+                assert a == action[g]
+                o.step(g, a)
+                assert o.canon_hash(g) == int(hashes[g])
+    dt = time.time() - t0
+    for e in engs:
+        assert e.stats()["capacity_faults"] == 0
+        e.close()
+    assert dt < 10.0, f"48 decision rounds of 32 games took {dt:.1f} s: launches are paying for scratch hand-over again"
+
+
 def test_config_c3_ga_loop_through_the_hip_path(tmp_path):
     """BASELINE configs[2] (C3): the GA driver loop of evo/evolution.py:60-111 -- mu = lambda = 128, 64 games per
     individual (ring schedule), N12M, seed 42 -- for two generations (8 192 + 16 384 games, 200 decisions each) through
