@@ -613,9 +613,9 @@ int monsoon_create(const monsoon_config* cfg, monsoon_t** out) {
   memset(&h->b, 0, sizeof(h->b));
   h->cfg = *cfg;
   h->var = var;
-  // one default for every build (MAX_DEPTH 40 levels of the recursive rules core, rules.h): handles of different builds
-  // in one process then ask for the same device-wide limit.  Stack sizes from 4 to 48 KiB measure the same.
-  if (h->cfg.stack_bytes <= 0) h->cfg.stack_bytes = 32768;
+  // per-lane stack: at least what the build's stack check assumes (state.h STACK_BYTES_MIN)
+  if (const char* e = getenv("MONSOON_STACK")) h->cfg.stack_bytes = atoi(e);   // experiments
+  if (h->cfg.stack_bytes < STACK_BYTES_MIN) h->cfg.stack_bytes = STACK_BYTES_MIN;
   h->device = cfg->device;
   memset(h->st_acc, 0, sizeof(h->st_acc));
   memset(h->st_base, 0, sizeof(h->st_base));

@@ -1311,7 +1311,7 @@ struct Engine {
   MSB_HD MSB_NOINLINE void run_ability_impl(int e, int spell, int pos_pk, bool src) {
     MSB_SCOPE(PS_RUN_ABILITY);
     int d = m.ld8(H_DEPTH);
-    if (d >= MAX_DEPTH) {
+    if (d >= MAX_DEPTH || !M::stack_ok()) {
       set_fault(FAULT_DEPTH);
       return;
     }
@@ -1540,7 +1540,7 @@ struct Engine {
   MSB_HD MSB_NOINLINE void move_impl(int e) {
     MSB_SCOPE(PS_MOVE);
     int d = m.ld8(H_DEPTH);
-    if (d >= MAX_DEPTH) {
+    if (d >= MAX_DEPTH || !M::stack_ok()) {
       set_fault(FAULT_DEPTH);
       return;
     }

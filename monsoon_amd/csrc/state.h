@@ -236,6 +236,7 @@ struct FlatMem {
   MSB_HD MSB_INL double ldfg(int g, int k) const { return ldf(g * 16 + k); }
   MSB_HD MSB_INL void stfg(int g, int k, double v) { stf(g * 16 + k, v); }
   MSB_HD MSB_INL static double wtab(int age) { return g_wtab.v[age & AGE_MAX]; }
+  MSB_HD MSB_INL static bool stack_ok() { return true; }   // the host stack is not a concern
   // order in which abilities run (scenario tests): a log the host oracle can switch on; compiled out of device code
   MSB_HD MSB_INL static void trace_ability(int card, int pos) {
 #if !defined(__HIPCC__)
@@ -252,6 +253,28 @@ struct FlatMem {
 };
 
 #if defined(__HIPCC__)
+// Per-lane stack of the recursive rules core on the device (hipLimitStackSize, a device-wide setting the host raises to
+// at least this before every launch).  Measured frames (ISA of round 2): kernel 0.6-3.4 KB, move 128-192 B, run_ability
+// 80 B, a card's ability <= 272 B, s203 608 B: 40 nested levels stay below 10 KB on the standard record; the extended
+// records add the memory copies (rem_deep_copy x REM_DEPTH, a 2.5 KB stream regeneration).  stack_ok() turns an overrun
+// -- should one ever come close -- into FAULT_DEPTH instead of a write into the next wavefront's stack.
+#if defined(MSB_EXT) && MSB_EXT == 2
+constexpr int STACK_BYTES_MIN = 32768;
+#elif defined(MSB_EXT) && MSB_EXT
+constexpr int STACK_BYTES_MIN = 24576;
+#else
+constexpr int STACK_BYTES_MIN = 16384;   // 32 KiB on this record costs 6 % (fewer wavefronts get scratch), 24 KiB nothing
+#endif
+constexpr int STACK_GUARD = STACK_BYTES_MIN - 4096;   // deepest call chain below a check + the largest leaf frame
+MSB_HD MSB_INL bool device_stack_ok() {
+#if defined(__HIP_DEVICE_COMPILE__)
+  uint32_t sp;
+  asm volatile("s_mov_b32 %0, s32" : "=s"(sp));   // s32: the stack pointer of the AMDGPU calling convention, bytes per lane
+  return sp <= (uint32_t)STACK_GUARD;
+#else
+  return true;
+#endif
+}
 // Device-only forms with explicit address spaces, so that hipcc emits ds_read/ds_write (LDS) and
 // global_load/global_store (HBM) instead of flat_* instructions behind non-inlined calls.
 #define MSB_AS_LDS __attribute__((address_space(3)))
@@ -309,6 +332,7 @@ struct LaneMem {   // this lane's private record among LANES interleaved ones
   MSB_HD MSB_INL static double ldfg(int g, int k) { return *(MSB_AS_LDS const double*)gb(g, k); }
   MSB_HD MSB_INL static void stfg(int g, int k, double v) { *(MSB_AS_LDS double*)gb(g, k) = v; }
   MSB_HD MSB_INL static double wtab(int age) { return lds_wtab(age); }
+  MSB_HD MSB_INL static bool stack_ok() { return device_stack_ok(); }
   MSB_HD MSB_INL static void trace_ability(int, int) {}
 };
 // The same with the ability log of the scenario tests switched on: {card, position} pairs appended to an LDS array
@@ -351,6 +375,7 @@ struct SharedMem {   // one contiguous record read by every lane of the wave (LD
   MSB_HD MSB_INL static double ldfg(int g, int k) { return ldf(g * 16 + k); }
   MSB_HD MSB_INL static void stfg(int g, int k, double v) { stf(g * 16 + k, v); }
   MSB_HD MSB_INL static double wtab(int age) { return lds_wtab(age); }
+  MSB_HD MSB_INL static bool stack_ok() { return device_stack_ok(); }
   MSB_HD MSB_INL static void trace_ability(int, int) {}
 };
 #endif
