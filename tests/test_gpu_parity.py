@@ -258,16 +258,22 @@ def test_numpy_stream_and_dot_known_answers_on_gpu(gold):
     eng.close()
 
 
-def test_reference_unit_tests_as_scenarios_on_gpu():
+@pytest.mark.parametrize("builds", ["standard+extended", "large"])
+def test_reference_unit_tests_as_scenarios_on_gpu(builds):
     """The reference's own 113 unit tests (112 card tests + the engine-level trigger-order / respawn test, test.py:53-147),
     recorded call by call on the reference (tests/golden/scenarios.json.gz): the HIP engine is put into the state the
     reference had (monsoon_debug_build), makes the one call (monsoon_debug_op) and must land on the REFERENCE's canonical
-    state and on the reference's order of ability activations -- fixture vs HIP, no oracle in between."""
+    state and on the reference's order of ability activations -- fixture vs HIP, no oracle in between.  Once on the
+    records a game normally runs on (standard; extended for ua20 / b005), once with every scenario on the large record."""
     import scenario_lib as S
     from monsoon_amd.cards import CARD_INDEX
     from monsoon_amd.engine import BatchEngine
     ext_cards = [CARD_INDEX["ua20"], CARD_INDEX["b005"]]
-    engs = {False: BatchEngine(2), True: BatchEngine(2, extended=True)}
+    if builds == "large":
+        big = BatchEngine(2, extended=2)
+        engs = {False: big, True: big}
+    else:
+        engs = {False: BatchEngine(2), True: BatchEngine(2, extended=True)}
     n_calls, n_tests = 0, 0
     for case in S.load():
         for k, rec in enumerate(case["records"]):
@@ -284,7 +290,7 @@ def test_reference_unit_tests_as_scenarios_on_gpu():
             n_calls += 1
         n_tests += 1
     assert n_tests == 113 + 7 and n_calls > 550   # + the quirk scenarios of SURVEY §0 (G6)
-    for e in engs.values():
+    for e in set(engs.values()):
         e.close()
 
 

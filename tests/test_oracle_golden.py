@@ -227,7 +227,8 @@ def test_quirk_spell_lands_one_tile_late(oracle_mod):
     assert seen > 0
 
 
-def test_reference_unit_tests_as_scenarios(oracle_mod):
+@pytest.mark.parametrize("builds", ["standard+extended", "large"])
+def test_reference_unit_tests_as_scenarios(oracle_mod, builds):
     """The reference's OWN tests: 112 `class <ID>Test(CardTestCase)` next to the cards and the
     engine-level BaseTestCase (test.py:53-147: LIFO order of a 16-unit U401 chain reaction, trigger order vs move order,
     respawn), recorded call by call on the reference (oracle/pyref/gen_scenarios.py; all 113 pass there).  For every
@@ -236,7 +237,11 @@ def test_reference_unit_tests_as_scenarios(oracle_mod):
     import scenario_lib as S
     from monsoon_amd.cards import CARD_INDEX
     ext_cards = [CARD_INDEX["ua20"], CARD_INDEX["b005"]]
-    orcs = {False: oracle_mod.Oracle(1), True: oracle_mod.Oracle(1, extended=True)}
+    if builds == "large":   # every scenario on the large record (the replay tier's build)
+        big = oracle_mod.Oracle(1, extended=2)
+        orcs = {False: big, True: big}
+    else:
+        orcs = {False: oracle_mod.Oracle(1), True: oracle_mod.Oracle(1, extended=True)}
     n_calls, n_tests, orders = 0, 0, 0
     for case in S.load():
         for k, rec in enumerate(case["records"]):
