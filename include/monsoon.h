@@ -109,7 +109,7 @@ int monsoon_status(monsoon_t* h, int32_t* out);
 int monsoon_game_faults(monsoon_t* h, uint8_t* out);
 
 /* Canonical state record of game idx (layout: monsoon_amd/csrc/canon.h), the comparand of the
- * bit-exactness tests.  buf must hold 1024 bytes. */
+ * bit-exactness tests.  buf must hold 2048 bytes (the standard and the extended record never need more than 1024). */
 int monsoon_state_export(monsoon_t* h, int32_t idx, uint8_t* buf, int32_t* len);
 
 /* copy.deepcopy(game) across the boundary (evo/game_adapter.py:280-287 clone_state): the COMPLETE device state of game

@@ -7,6 +7,7 @@
 namespace msb {
 
 constexpr int CANON_MAX = 4 + 8 + 2 * (12 + 3 * HAND_CAP + 11 * DECK_CAP) + 20 * 11 + 4;
+static_assert(CANON_MAX <= 2048, "monsoon_state_export hands out at most 2048 bytes (include/monsoon.h)");
 
 template <class M>
 MSB_HD inline int canon_record(const Engine<M>& g, uint32_t next_u32, uint8_t* out) {

@@ -34,7 +34,11 @@ constexpr int DECK_SIZE = 12;  // cards per deck at construction (games/stormbou
 // EXTENDED record (-DMSB_EXT=1: libmonsoon_hip_ext.so / liboracle_ext.so) adds room for ua20's extra
 // single-use deck cards (cards/ua20.py:27-32) and for b005's remembered deep copies (cards/b005.py:14-33).
 #if defined(MSB_EXT) && MSB_EXT
+#if MSB_EXT == 2
+constexpr int DECK_CAP = 48;   // ua20 keeps appending single-use copies (cards/ua20.py:27-32): 2 of 131 072 C5 games pass 32 entries
+#else
 constexpr int DECK_CAP = 32;
+#endif
 #if defined(MSB_CAP_REM)       // capacity studies (scripts/c5_capacity.py)
 constexpr int REM_LISTS = MSB_CAP_REM, WORLD_CAP = MSB_CAP_WORLD;
 #elif MSB_EXT == 2             // the LARGE record: where monsoon_rollout replays the games the extended record cannot hold
@@ -127,7 +131,7 @@ constexpr int P_DECK_N = 10;
 // ua20's duplicate structures make list.remove() take a different (equal) object than the one drawn
 // (player.py:52, structure.py:18-19): the same object can then sit in the hand and in the deck, or twice
 // in the deck, and Player.reweight (player.py:57-59) touches it once per list position.
-constexpr int INST_CAP = 40;   // >= HAND_CAP + DECK_CAP distinct objects can be listed
+constexpr int INST_CAP = DECK_CAP + 8;   // >= HAND_CAP + DECK_CAP distinct objects can be listed
 constexpr int P_HAND = 12;                       // HAND_CAP x u8 instance id
 constexpr int P_DECK = P_HAND + HAND_CAP;        // DECK_CAP x u8 instance id
 constexpr int P_INST = (P_DECK + DECK_CAP + 3) & ~3;          // INST_CAP x {card, cost, flags, x}

@@ -121,7 +121,7 @@ class BatchEngine:
         return out
 
     def export(self, i):
-        buf = np.zeros(1024, dtype=np.uint8)
+        buf = np.zeros(2048, dtype=np.uint8)
         ln = ctypes.c_int32()
         self._ck(self.lib.monsoon_state_export(self.h, i, _ptr(buf), ctypes.byref(ln)), "monsoon_state_export")
         return buf[:ln.value].tobytes()

@@ -56,7 +56,7 @@ class Mirror:
         return f, r.value, d.value
 
     def canon(self):
-        buf = (ctypes.c_uint8 * 1024)()
+        buf = (ctypes.c_uint8 * 2048)()
         n = LIB.orc_canon(self.h, 0, buf)
         return bytes(buf[:n])
 

@@ -410,7 +410,7 @@ def gen_initial():
     for deck in ("N12V", "N12M", "S12"):
         for seed in (0, 1, 42, 123, 2**32 - 1):
             c = H.canon(H.make_game(seed, H.DECKS[deck], H.DECKS[deck]))
-            buf = np.zeros(1024, dtype=np.uint8)
+            buf = np.zeros(2048, dtype=np.uint8)
             buf[:len(c)] = np.frombuffer(c, dtype=np.uint8)
             recs.append(buf)
             lens.append(len(c))

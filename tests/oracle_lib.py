@@ -126,7 +126,7 @@ class Oracle:
         return f
 
     def canon(self, i):
-        buf = np.zeros(1024, dtype=np.uint8)
+        buf = np.zeros(2048, dtype=np.uint8)
         n = self.L.orc_canon(self.h, i, _p(buf))
         return buf[:n].tobytes()
 
