@@ -352,7 +352,9 @@ def gen_heuristic_pool(n_games, max_turns, jobs, seed0=700, ext=False):
 def gen_heuristic_c5(indices, max_turns, jobs):
     """Heuristic self-play of chosen games of the C5 family (tests/c5_games.py: seed 90000 + k, decks drawn by
     RandomState(k ^ 0x9E3779B9) from the 109 observable cards): games whose nested b005 memories outgrow the product's
-    extended record -- the product replays them on its large record (libmonsoon_hip_big.so) and must reproduce these."""
+    extended record -- the product replays them on its large record (libmonsoon_hip_big.so) and must reproduce these.
+    29409 is a game the reference itself ends with a RecursionError (the product: FAULT_DEPTH at the same decision); 1374
+    takes the reference more than ten minutes and is left out by the time limit."""
     pool = [c for c in H.CARD_IDS if c not in ("up01", "up02", "up03")]
     tasks, decks = [], []
     for k in indices:
@@ -394,7 +396,7 @@ def gen_heuristic_c5(indices, max_turns, jobs):
             out[k] += rec[k]
         out["offsets"].append(len(out["action"]))
     np.savez_compressed(
-        os.path.join(GOLD, "trace_heuristic_c5_big.npz"), seeds=np.array(out["seeds"], dtype=np.uint32),
+        os.path.join(GOLD, os.environ.get("C5_OUT", "trace_heuristic_c5_big.npz")), seeds=np.array(out["seeds"], dtype=np.uint32),
         offsets=np.array(out["offsets"], dtype=np.int64), result=np.array(out["result"], dtype=np.int8),
         fault=np.array(out["fault"], dtype=np.uint8),
         action=np.array(out["action"], dtype=np.uint8), hash=np.array(out["hash"], dtype=np.uint64),
@@ -495,7 +497,8 @@ def main():
         "heuristic_S12": lambda: gen_heuristic(16, 200, args.jobs, "S12", None, 300),
         "heuristic_pool": lambda: gen_heuristic_pool(24, 120, args.jobs),
         "heuristic_pool_ext": lambda: gen_heuristic_pool(16, 120, args.jobs, 900, ext=True),
-        "heuristic_c5_big": lambda: gen_heuristic_c5([264, 1374, 2103, 2458, 2649, 3525, 3540, 6149, 3691, 4215, 4593, 5070], 200, args.jobs),
+        "heuristic_c5_big": lambda: gen_heuristic_c5([int(k) for k in os.environ["C5_GAMES"].split(",")] if os.environ.get("C5_GAMES") else
+                                                     [264, 1374, 2103, 2458, 2649, 3525, 3540, 6149, 3691, 4215, 4593, 5070, 29409], 200, args.jobs),
         "heuristic_IRONCLAD": lambda: gen_heuristic(12, 120, args.jobs, "IRONCLAD", "SWARM", 400),
         "decks": gen_decks,
     }

