@@ -174,6 +174,8 @@ def main():
             print("MISMATCH", err)
             if pool:
                 print("   decks", d0, d1)
+        if (k + 1) % 10 == 0:
+            print(f"progress: {k + 1} games, {total} steps, {bad} mismatching games", file=sys.stderr, flush=True)
     print(f"{args.games} games, {total} steps, {bad} mismatching games")
     return 1 if bad else 0
 
