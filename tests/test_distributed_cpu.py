@@ -102,3 +102,39 @@ def test_bench_refuses_more_gpus_than_the_machine_has():
     rc, lines, err = _run_bench(["--gpus", "2", "--steps", "1", "--warmup", "0", "--no-cpu"], {})
     assert rc != 0 and lines == []
     assert "refusing" in err
+
+
+def test_replace_capacity_faulted_rewrites_only_the_overflowing_rows():
+    """Host logic of the replay tier (monsoon_amd/fitness.py): rows with a fault code >= 16 are replaced by the replay's,
+    their first attempt's contribution to the per-individual counts is taken out, everything else is untouched."""
+    import numpy as np
+    from monsoon_amd.fitness import MATCH_DTYPE, replace_capacity_faulted
+    m = np.zeros(6, dtype=MATCH_DTYPE)
+    m["p1"] = [0, 0, 1, 1, 2, 2]
+    m["p2"] = [1, 2, 0, 2, 0, 1]
+    results = np.array([0, -1, 1, -1, 0, -1], dtype=np.int8)      # games 1 and 3 were cut short as draws ...
+    steps = np.array([50, 7, 60, 9, 70, 200], dtype=np.int32)
+    faults = np.array([0, 16, 0, 22, 1, 0], dtype=np.uint8)       # ... by capacity codes; code 1 is the reference's own exception
+    counts = np.zeros((3, 3), dtype=np.int64)
+    for k in range(6):
+        counts[m["p1"][k], 0] += results[k] == 0
+        counts[m["p1"][k], 1] += results[k] == -1
+        counts[m["p1"][k], 2] += 1
+    seen = {}
+
+    def replay(sub):
+        seen["sub"] = sub.copy()
+        c = np.zeros((3, 3), dtype=np.int64)
+        r = np.array([0, 1], dtype=np.int8)                        # replayed: game 1 is a win for p1 = 0, game 3 a loss for p1 = 1
+        for j in range(2):
+            c[sub["p1"][j], 0] += r[j] == 0
+            c[sub["p1"][j], 1] += r[j] == -1
+            c[sub["p1"][j], 2] += 1
+        return c, r, np.array([120, 130], dtype=np.int32), np.array([0, 16], dtype=np.uint8)
+
+    n = replace_capacity_faulted(counts, results, steps, faults, m, replay)
+    assert n == 2 and list(seen["sub"]["p2"]) == [2, 2]
+    assert results.tolist() == [0, 0, 1, 1, 0, -1] and steps.tolist() == [50, 120, 60, 130, 70, 200]
+    assert faults.tolist() == [0, 0, 0, 16, 1, 0]                  # what not even the replay could hold stays flagged
+    assert counts.tolist() == [[2, 0, 2], [0, 0, 2], [1, 1, 2]]
+    assert replace_capacity_faulted(counts, results, steps, np.zeros(6, dtype=np.uint8), m, replay) == 0

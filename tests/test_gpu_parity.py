@@ -594,6 +594,32 @@ def test_handles_of_several_builds_alive_at_once():
     assert dt < 10.0, f"48 decision rounds of 32 games took {dt:.1f} s: launches are paying for scratch hand-over again"
 
 
+def test_own_stream_mode_gives_the_same_games():
+    """MONSOON_OWN_STREAM=1 (a stream per handle instead of the device's default stream, include/monsoon.h) only changes
+    where the launches are queued: a child process in that mode reaches the same states."""
+    import subprocess
+    import sys
+    code = (
+        "import sys, numpy as np; sys.path.insert(0, %r);"
+        "from monsoon_amd.engine import BatchEngine; from monsoon_amd.cards import deck_indices;"
+        "d = deck_indices('N12M'); e = BatchEngine(64); e.reset(np.arange(64, dtype=np.uint32) + 3, np.stack([d, d]));"
+        "w = np.random.RandomState(2024).uniform(0, 1, 10);"
+        "[e.decide(w) for _ in range(6)];"
+        "assert e.lib.monsoon_stream(e.h) %s;"
+        "print(' '.join(str(int(h)) for h in e.state_hash()))"
+    )
+    import os
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for own in ("1", "0"):
+        env = dict(os.environ, MONSOON_OWN_STREAM=own)
+        r = subprocess.run([sys.executable, "-c", code % (repo, "is not None" if own == "1" else "is None")], env=env, capture_output=True, text=True,
+                           timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append(r.stdout.strip().splitlines()[-1])
+    assert outs[0] == outs[1] and len(outs[0].split()) == 64
+
+
 def test_config_c3_ga_loop_through_the_hip_path(tmp_path):
     """BASELINE configs[2] (C3): the GA driver loop of evo/evolution.py:60-111 -- mu = lambda = 128, 64 games per
     individual (ring schedule), N12M, seed 42 -- for two generations (8 192 + 16 384 games, 200 decisions each) through
