@@ -9,11 +9,12 @@ sys.path.insert(0,'/root/repo'); sys.path.insert(0,'/root/repo/tests')
 import oracle_lib
 oracle_lib.LIB_PATH = '/tmp/liboracle_asan.so'
 oracle_lib.LIB_PATH_EXT = '/tmp/liboracle_ext_asan.so'
+oracle_lib.LIB_PATH_BIG = '/tmp/liboracle_big_asan.so'
 import numpy as np
 from monsoon_amd.cards import CARD_IDS, CARD_INDEX, supported_pool, deck_indices
 W0=np.random.RandomState(2024).uniform(0,1,10)
 # heuristic rollouts on named decks and random decks, both builds
-for ext in (False, True):
+for ext in (False, True, 2):
     pool=np.array([i for i,c in enumerate(CARD_IDS) if c not in ("up01","up02","up03") and (ext or c not in ("ua20","b005"))],dtype=np.uint8)
     orc=oracle_lib.Oracle(1, extended=ext)
     n=0
@@ -28,7 +29,12 @@ for ext in (False, True):
     # include up0x decks (observation raises)
     d=deck_indices("N12M").copy(); d[0]=CARD_INDEX["up01"]
     orc.reset(0,1,d,d); orc.rollout(0,W0,W0,50)
-    print("ext" if ext else "std", "look-ahead steps under ASan/UBSan:", n, flush=True)
+    if ext:   # games of the C5 family whose nested b005 memories overflow the extended record (capacity paths, worlds, GC)
+        from c5_games import C5_OVERFLOWING, c5_games
+        m, pairs = c5_games(C5_OVERFLOWING)
+        for k in range(len(C5_OVERFLOWING)):
+            orc.reset(0, int(m["seed"][k]), pairs[k, 0], pairs[k, 1]); r = orc.rollout(0, W0, W0, 200); n += r['lookahead']
+    print({False: "std", True: "ext", 2: "big"}[ext], "look-ahead steps under ASan/UBSan:", n, flush=True)
 print("sanitizers clean (rollouts)")
 # the scenario fixtures (the reference's own tests, call by call): state builder + single engine calls, both builds
 import scenario_lib as S
