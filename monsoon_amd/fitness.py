@@ -141,10 +141,11 @@ class FitnessEvaluator:
             return counts.astype(np.int64), results, steps, eng.rollout_faults(len(sub))
 
         counts, results, steps, faults = play(ext, matches)
-        if ext:
-            # nested b005 memories are deep copies of the whole game (cards/b005.py:14-33, card.py:71-75): the few games
-            # whose copies outgrow the extended record (128 entity slots) are replayed on the large one (254)
-            self.capacity_replays += replace_capacity_faulted(counts, results, steps, faults, matches, lambda sub: play(2, sub))
+        # nested b005 memories are deep copies of the whole game (cards/b005.py:14-33, card.py:71-75): the few games whose
+        # copies outgrow the extended record (128 entity slots) are replayed on the large one (254).  The standard
+        # record (28 slots) has never been seen to overflow; if it did, the same ladder applies: standard -> extended -> large.
+        for tier in range(ext + 1, 3):
+            self.capacity_replays += replace_capacity_faulted(counts, results, steps, faults, matches, lambda sub, t=tier: play(t, sub))
         self.capacity_faults += int((faults >= CAPACITY_CODE).sum())
         self.last_rollout = (results, steps, faults)
         return counts

@@ -35,8 +35,8 @@ def oracle_rollout_fn(weights, matches, deck_pairs, max_turns, want_results=Fals
     matches = np.asarray(matches)
     ext = int(bool(needs_extended(np.asarray(deck_pairs, dtype=np.uint8).reshape(-1, 2, 12))))
     counts, results, steps, faults = oracle_rollout_tier(weights, matches, deck_pairs, max_turns, ext)
-    if ext:
-        replace_capacity_faulted(counts, results, steps, faults, matches, lambda sub: oracle_rollout_tier(weights, sub, deck_pairs, max_turns, 2))
+    for tier in range(ext + 1, 3):
+        replace_capacity_faulted(counts, results, steps, faults, matches, lambda sub, t=tier: oracle_rollout_tier(weights, sub, deck_pairs, max_turns, t))
     if want_faults:
         return counts, results, steps, faults
     return (counts, results, steps) if want_results else counts
