@@ -113,6 +113,7 @@ class FitnessEvaluator:
         self._rollout_fn = rollout_fn
         self._device = device
         self._engines = {}
+        self.eval_times = []            # wall seconds of every evaluate_population call (the first one creates the engine)
         self.capacity_replays = 0       # games replayed on the large record
         self.capacity_faults = 0        # games not even the large record could hold (their fault code ends them as draws)
 
@@ -218,6 +219,7 @@ class FitnessEvaluator:
                 counts = self._all_reduce_counts(dist, counts)
         self.total_games += len(matches)
         self.total_time += time.time() - start
+        self.eval_times.append(time.time() - start)
         fitness = fitness_from_counts(counts[:n], per_individual)
         self._update_hall_of_fame(population, fitness)
         return fitness

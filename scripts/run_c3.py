@@ -26,4 +26,5 @@ st = res["evaluation_stats"]
 print(json.dumps({"config": "C3", "generations": res["generations"], "wall_s": dt, "games": st["total_games"],
                   "env_steps": st["env_steps"], "env_steps_per_s": st["env_steps"] / st["total_time"],
                   "games_per_s": st["games_per_second"], "best_fitness": res["best_fitness"],
-                  "mean_fitness": res["final_stats"]["mean_fitness"]}))
+                  "mean_fitness": res["final_stats"]["mean_fitness"],
+                  "evaluate_ms_per_generation": [round(1e3 * t, 1) for t in eng.fitness_evaluator.eval_times]}))
