@@ -38,7 +38,7 @@ typedef struct {
   int32_t max_games;       /* capacity of the batch */
   int32_t lanes_per_game;  /* candidate lanes (successor states stepped at once) per game: 4, 8, 16, 32 or 64; 0 = default.
                               Must be a kernel variant of the build (monsoon_amd/csrc/variants.def), else create fails */
-  int32_t stack_bytes;     /* per-lane scratch stack for the rules core's recursion (0 = default) */
+  int32_t stack_bytes;     /* ignored since the rules core keeps an explicit work stack (kept for ABI compatibility) */
 } monsoon_config;
 
 /* One scheduled game of a fitness evaluation (evo/fitness.py:53-59,133-157). */

@@ -2,7 +2,7 @@
 // judged on (same byte layout as oracle/pyref/harness.py::canon builds from the reference's
 // objects).  Used by monsoon_state_export (product) and by the oracle.
 #pragma once
-#include "rules.h"
+// (included behind a rules core: the product's rules.h or, in the oracle, oracle/recursive/rules.h)
 
 namespace msb {
 

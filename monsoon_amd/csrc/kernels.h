@@ -26,6 +26,7 @@
 #include <stdint.h>
 
 #include "../../include/monsoon.h"
+#include "rules.h"
 #include "canon.h"
 
 namespace msbk {
@@ -66,7 +67,17 @@ struct DevBuffers {
   double* best;        // [cap]
   int* pop;            // [2][POP_PARTS * POP_STRIDE] game-index counters of the persistent k_decide, alternating between launches
   unsigned long long* prof;   // [cap][..] phase cycles, scope cycles, scope calls (profiling build), profiling build only (else null)
+  uint32_t* wk_ovf;    // overflow blocks of the rules core's work stack: [workgroup][SK_CAP - SKW][lanes stepping games in it]
 };
+
+// Work-stack words per game kept in LDS (state.h LaneMem): the frames of a step with a handful of nested abilities.
+// Deeper stacks continue in the workgroup's overflow block in HBM.
+#if defined(MSB_SKW)
+constexpr int SKW = MSB_SKW;
+#else
+constexpr int SKW = 32;
+#endif
+constexpr int OVF_WORDS = SK_CAP - SKW;   // per stepping lane
 
 enum { ST_LOOKAHEAD = 0, ST_DECISIONS = 1, ST_FINISHED = 2, ST_FAULTS = 3, ST_CAPFAULTS = 4, ST_LACAPFAULTS = 5, ST_N = 6, ST_PROF = 8, ST_WORDS = 32, PROF_WORDS = 138 };
 // Phase timing of k_decide (profiling build only, -DMSB_PROF=1 -> libmonsoon_hip_prof.so; never the product):
@@ -184,7 +195,8 @@ constexpr int LDS_ORIGIN = LDS_RECORDS;
 // Hot kernel: a wavefront takes a game, keeps its record in LDS and plays up to `rounds` decisions of it (look-ahead +
 // score + argmax + commit each) before it writes the record back and takes the next game.
 // Dynamic LDS map (bytes): weight table | [PRIV, +SG*U*16) candidate records, lane-interleaved in 16-byte granules |
-// the game's current record | the parked best successor | 10 weights + 10 "before" + 10 "best after" features
+// the game's current record | the parked best successor | 10 weights + 10 "before" + 10 "best after" features |
+// the candidates' work stacks (SKW words each, interleaved word by word)
 // ------------------------------------------------------------------------------------------------
 __device__ MSB_INL int nth_set_bit(const uint64_t mask[3], int k) {
   for (int w = 0; w < 3; w++) {
@@ -206,7 +218,8 @@ struct DecideLds {
   static constexpr int PAR = PRIV + PRIV_BYTES;      // the game's current record
   static constexpr int BEST = PAR + SG * 16;         // best successor so far of a decision that needs several passes
   static constexpr int WF = BEST + SG * 16;          // 10 weights + 10 "before" features + 10 features of the best successor (f64)
-  static constexpr int TOTAL = WF + 240;
+  static constexpr int SKB = WF + 240;               // work stacks of the U candidate lanes
+  static constexpr int TOTAL = SKB + U * SKW * 4;
 };
 
 __device__ MSB_INL unsigned long long uni64(unsigned long long v) {   // a wave-uniform 64-bit value into scalar registers
@@ -218,10 +231,10 @@ __device__ MSB_INL unsigned long long uni64(unsigned long long v) {   // a wave-
 // Up to `rounds` decisions of game g by the calling wavefront.  The record lives in LDS from the first decision to
 // the last; HBM sees one read and one write of it per call.
 template <int U>
-__device__ void play_game(const DevBuffers& b, const int g, const int lane, int max_turns, int rounds, int write_scores) {
+__device__ MSB_INL void play_game(const DevBuffers& b, const int g, const int lane, int max_turns, int rounds, int write_scores) {
   typedef DecideLds<U> L;
   typedef Engine<SharedMem<L::PAR>> ParEngine;
-  typedef Engine<LaneMem<U, L::PRIV>> CandEngine;
+  typedef Engine<LaneMem<U, L::PRIV, L::SKB, SKW>> CandEngine;
   GameMeta meta = b.meta[g];
   if (meta.result != -2) {
     if (lane == 0) {
@@ -440,21 +453,20 @@ constexpr int POP_PARTS = 8, POP_STRIDE = 32;
 template <int U, int WPE>
 __global__ void __launch_bounds__(64, WPE) k_play(DevBuffers b, int n, int max_turns, int rounds, int write_scores, int persistent, int parity) {
   const int lane = threadIdx.x;
-  lds_init_wtab();
-  if (!persistent) {
-    if ((int)blockIdx.x < n) play_game<U>(b, blockIdx.x, lane, max_turns, rounds, write_scores);
-    return;
-  }
+  lds_init_wtab(b.wk_ovf + (size_t)blockIdx.x * (U * OVF_WORDS));
+  // one body for both forms (play_game is the whole rules core, inlined once): the non-persistent form is a "range" of
+  // one game that is never refilled
   int* mine = b.pop + parity * POP_PARTS * POP_STRIDE;
   int* other = b.pop + (parity ^ 1) * POP_PARTS * POP_STRIDE;
-  if (blockIdx.x == 0 && lane < POP_PARTS) other[lane * POP_STRIDE] = 0;
+  if (persistent && blockIdx.x == 0 && lane < POP_PARTS) other[lane * POP_STRIDE] = 0;
   const int part = blockIdx.x % POP_PARTS, rank = blockIdx.x / POP_PARTS;
   const int waves = ((int)gridDim.x - part + POP_PARTS - 1) / POP_PARTS;   // wavefronts working on this range
-  const int lo = (int)((long long)n * part / POP_PARTS), hi = (int)((long long)n * (part + 1) / POP_PARTS);
-  int t = lo + rank;
+  const int lo = persistent ? (int)((long long)n * part / POP_PARTS) : 0;
+  const int hi = persistent ? (int)((long long)n * (part + 1) / POP_PARTS) : n;
+  int t = persistent ? lo + rank : (int)blockIdx.x;
   while (t < hi) {
     int nxt = 0x7fffffff;
-    if (lane == 0) nxt = lo + waves + atomicAdd(&mine[part * POP_STRIDE], 1);
+    if (persistent && lane == 0) nxt = lo + waves + atomicAdd(&mine[part * POP_STRIDE], 1);
     play_game<U>(b, t, lane, max_turns, rounds, write_scores);
     __syncthreads();   // the LDS image is reused by the next game
     t = __builtin_amdgcn_readfirstlane(nxt);

@@ -39,11 +39,12 @@ constexpr int API_LANES = 64;
 #endif
 // LDS address 0 is avoided on purpose: an integer constant 0 cast to an LDS pointer is the null pointer,
 // which is not address 0 on this target; every region starts at LDS_ORIGIN.
-constexpr int API_LDS_BYTES = LDS_ORIGIN + SG * API_LANES * 16;
-typedef LaneMem<API_LANES, LDS_ORIGIN> ApiMem;
+constexpr int API_SKB = LDS_ORIGIN + SG * API_LANES * 16;   // the lanes' work stacks behind their records
+constexpr int API_LDS_BYTES = API_SKB + API_LANES * SKW * 4;
+typedef LaneMem<API_LANES, LDS_ORIGIN, API_SKB, SKW> ApiMem;
 typedef Engine<ApiMem> ApiEngine;
 #define API_GAME_INDEX()                                  \
-  lds_init_wtab();                                        \
+  lds_init_wtab(b.wk_ovf + (size_t)blockIdx.x * (API_LANES * OVF_WORDS)); \
   if ((int)threadIdx.x >= API_LANES) return;              \
   int g = blockIdx.x * API_LANES + threadIdx.x;           \
   if (g >= n) return;
@@ -239,10 +240,15 @@ __global__ void __launch_bounds__(256) k_stats(DevBuffers b, int n, unsigned lon
   }
 }
 
-// per game: the fault that stopped it, else the first build-limit fault one of its look-aheads hit (0 = none)
+// per game: a build-limit code (>= FAULT_CAPACITY) whenever the game met one -- as the fault that stopped it or inside a
+// look-ahead (that action scored 0.0 where the reference computes a score, so the game may have left the reference's
+// line even if it later ended with one of the reference's own exceptions) -- else the fault that stopped it (0 = none)
+__device__ inline int reported_fault(const GameMeta& m) {
+  return m.fault >= FAULT_CAPACITY ? m.fault : (m.la_fault ? m.la_fault : m.fault);
+}
 __global__ void k_faults(DevBuffers b, int n, uint8_t* out) {
   int g = blockIdx.x * blockDim.x + threadIdx.x;
-  if (g < n) out[g] = b.meta[g].fault ? b.meta[g].fault : b.meta[g].la_fault;
+  if (g < n) out[g] = (uint8_t)reported_fault(b.meta[g]);
 }
 
 __global__ void k_clear_scores(double* scores, size_t n) {
@@ -283,18 +289,19 @@ __global__ void k_collect(DevBuffers b, int n, int32_t* counts, int8_t* results,
   if (!on) return;
   if (results) results[m.match] = (int8_t)r;
   if (steps) steps[m.match] = m.steps;
-  if (faults) faults[m.match] = m.fault ? m.fault : m.la_fault;
+  if (faults) faults[m.match] = (uint8_t)reported_fault(m);
 }
 
 // monsoon_debug_build / monsoon_debug_op (diagnostics; scenario tests): ONE lane runs scenario.inc on game g.  The
 // engine of this kernel logs the order in which abilities run (TraceLaneMem) -- the product kernels' engines do not.
 constexpr int DBG_TRACE_CAP = 256;
 constexpr int DBG_TRACE = LDS_ORIGIN + SG * 16;                      // u32 count, then {card, position} pairs
-constexpr int DBG_LDS_BYTES = DBG_TRACE + 4 + 8 * DBG_TRACE_CAP;
-typedef Engine<TraceLaneMem<1, LDS_ORIGIN, DBG_TRACE, DBG_TRACE_CAP>> DbgEngine;
+constexpr int DBG_SKB = DBG_TRACE + 4 + 8 * DBG_TRACE_CAP;          // the one lane's work stack
+constexpr int DBG_LDS_BYTES = DBG_SKB + SKW * 4;
+typedef Engine<TraceLaneMem<1, LDS_ORIGIN, DBG_SKB, SKW, DBG_TRACE, DBG_TRACE_CAP>> DbgEngine;
 __global__ void __launch_bounds__(64) k_debug(DevBuffers b, int g, int build, uint32_t seed, uint32_t stream_pos, const int32_t* stream,
                                                int32_t* out /* fault, n_log, pairs... */) {
-  lds_init_wtab();
+  lds_init_wtab(b.wk_ovf);   // one lane, one block: the first words of the overflow buffer
   if (threadIdx.x != 0) return;
   DbgEngine e;
   MSB_AS_LDS int32_t* tr = (MSB_AS_LDS int32_t*)(uintptr_t)DBG_TRACE;
@@ -411,6 +418,7 @@ struct monsoon {
   DevBuffers b;
   const VariantOps* var = nullptr;   // hot-kernel variant: candidate lanes per game, waves per SIMD
   int parity = 0;     // which of b.pop the next k_decide launch uses
+  size_t ovf_lanes = 0;   // stepping lanes b.wk_ovf has room for (OVF_WORDS words each)
   unsigned long long st_acc[ST_N], st_base[ST_N];   // statistics: totals of earlier batches, baseline of the loaded one
   int grid_waves = 0; // persistent grid size of k_decide (resident wavefronts), 0 = not yet queried
   int n = 0;          // games loaded by the last reset
@@ -517,7 +525,7 @@ void monsoon_destroy(monsoon_t* h) {
   if (!h) return;
   hipSetDevice(h->device);
   if (h->stream) hipStreamSynchronize(h->stream);
-  void* ptrs[] = {h->b.state, h->b.rng_out, h->b.rng_mt, h->b.meta, h->b.weights, h->b.stats, h->b.scores, h->b.best, h->b.prof, h->b.pop,
+  void* ptrs[] = {h->b.state, h->b.rng_out, h->b.rng_mt, h->b.meta, h->b.weights, h->b.stats, h->b.scores, h->b.best, h->b.prof, h->b.pop, h->b.wk_ovf,
                   h->d_bytes, h->d_decks, h->d_factions, h->d_seeds, h->d_masks, h->d_i32, h->d_f64, h->d_p1, h->d_p2, h->d_int,
                   h->d_counts, h->d_results, h->d_steps};
   for (void* p : ptrs)
@@ -556,6 +564,10 @@ static int create_impl(monsoon* h) {
   HIP_TRY(h, hipMalloc(&h->b.stats, ST_WORDS * sizeof(unsigned long long)));
   HIP_TRY(h, hipMemset(h->b.stats, 0, ST_WORDS * sizeof(unsigned long long)));
   HIP_TRY(h, hipMalloc(&h->b.best, cap * sizeof(double)));
+  // overflow blocks of the work stack (kernels.h): the lane-per-game API kernels step up to `cap` games at once (rounded
+  // up to whole workgroups); launch_play grows the buffer once it knows its grid
+  h->ovf_lanes = ((cap + API_LANES - 1) / API_LANES) * (size_t)API_LANES;
+  HIP_TRY(h, hipMalloc(&h->b.wk_ovf, h->ovf_lanes * OVF_WORDS * 4));
   HIP_TRY(h, hipMalloc(&h->b.pop, 2 * 8 * 32 * sizeof(int)));
   HIP_TRY(h, hipMemset(h->b.pop, 0, 2 * 8 * 32 * sizeof(int)));
 #if defined(MSB_PROF) && MSB_PROF
@@ -613,9 +625,8 @@ int monsoon_create(const monsoon_config* cfg, monsoon_t** out) {
   memset(&h->b, 0, sizeof(h->b));
   h->cfg = *cfg;
   h->var = var;
-  // per-lane stack: at least what the build's stack check assumes (state.h STACK_BYTES_MIN)
-  if (const char* e = getenv("MONSOON_STACK")) h->cfg.stack_bytes = atoi(e);   // experiments
-  if (h->cfg.stack_bytes < STACK_BYTES_MIN) h->cfg.stack_bytes = STACK_BYTES_MIN;
+  // cfg.stack_bytes is ignored: the rules core keeps its own work stack (LDS + b.wk_ovf) and the kernels need no
+  // per-lane stack in scratch memory
   h->device = cfg->device;
   memset(h->st_acc, 0, sizeof(h->st_acc));
   memset(h->st_base, 0, sizeof(h->st_base));
@@ -636,18 +647,8 @@ int monsoon_variant(monsoon_t* h, int32_t* lanes_per_game, int32_t* waves_per_si
   return MONSOON_OK;
 }
 
-// Make the handle's device current and its per-lane stack available.  The stack limit is a DEVICE-wide setting: the last
-// handle created, of whatever build, would otherwise decide it for everybody, and a kernel of the recursive rules core
-// that runs with less stack than its build was given overruns it.  The limit is only ever raised (10 us when it happens).
-static hipError_t bind_device(monsoon_t* h) {
-  hipError_t e = hipSetDevice(h->device);
-  if (e != hipSuccess) return e;
-  size_t cur = 0;
-  e = hipDeviceGetLimit(&cur, hipLimitStackSize);
-  if (e != hipSuccess) return e;
-  if (cur < (size_t)h->cfg.stack_bytes) e = hipDeviceSetLimit(hipLimitStackSize, (size_t)h->cfg.stack_bytes);
-  return e;
-}
+// Make the handle's device current.
+static hipError_t bind_device(monsoon_t* h) { return hipSetDevice(h->device); }
 
 static int check_ready(monsoon_t* h) {
   if (!h) return MONSOON_ERR_ARG;
@@ -657,7 +658,7 @@ static int check_ready(monsoon_t* h) {
   }
   hipError_t e = bind_device(h);
   if (e != hipSuccess) {
-    h->err = std::string("hipSetDevice / stack limit: ") + hipGetErrorString(e);
+    h->err = std::string("hipSetDevice: ") + hipGetErrorString(e);
     return MONSOON_ERR_DEVICE;
   }
   return MONSOON_OK;
@@ -1086,8 +1087,17 @@ static int launch_play(monsoon_t* h, int n, int max_turns, int rounds, int write
   // the persistent form needs a wavefront for every one of its POP_PARTS ranges
   const int pers = (g_persistent && grid < n && grid >= POP_PARTS) ? 1 : 0;
   if (!pers) grid = n;
+  if ((size_t)grid * v->lanes > h->ovf_lanes) {   // work-stack overflow blocks for every workgroup of this grid
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    HIP_TRY(h, hipFree(h->b.wk_ovf));
+    h->b.wk_ovf = nullptr;
+    h->ovf_lanes = (size_t)grid * v->lanes;
+    HIP_TRY(h, hipMalloc(&h->b.wk_ovf, h->ovf_lanes * OVF_WORDS * 4));
+  }
   v->play(grid, lds, h->stream, h->b, n, max_turns, rounds, write_scores, pers, h->parity);
-  h->parity ^= 1;
+  // Only a persistent launch consumes its counter set and clears the other one: a non-persistent launch in between
+  // must leave the parity alone, or the next persistent launch would start from the stale counts of the one before.
+  if (pers) h->parity ^= 1;
   HIP_TRY(h, hipGetLastError());
   if (timed) HIP_TRY(h, hipEventRecord(h->ev_pool[slot].second, h->stream));
   return MONSOON_OK;

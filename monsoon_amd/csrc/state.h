@@ -157,7 +157,14 @@ constexpr int WT_LDS = 928;      // behind the function-scope counters of the pr
 #else
 constexpr int WT_LDS = 16;       // LDS address 0 is avoided (the null LDS pointer)
 #endif
-constexpr int LDS_RECORDS = WT_LDS + 8 * WT_LDS_N;   // first LDS byte the kernels may use for records
+constexpr int WK_OVF_LDS = WT_LDS + 8 * WT_LDS_N;    // u64: global address of this workgroup's work-stack overflow block
+constexpr int LDS_RECORDS = WK_OVF_LDS + 16;         // first LDS byte the kernels may use for records
+// The work stack of the rules core (rules.h "Control flow"): SK_CAP 32-bit words per game.  On the device the first SKW
+// words of a lane's stack live in LDS (lane-interleaved like the record), deeper frames -- a chain of more than about a
+// dozen nested abilities -- spill to a per-workgroup block in HBM.  A step needs SK_MARGIN free words whenever it enters
+// an ability or a move (the two places that also count the reference's recursion depth), else it ends with FAULT_DEPTH.
+constexpr int SK_CAP = 512;
+constexpr int SK_MARGIN = 48;
 // card-instance flags (hand/deck entries {card, cost, flags, x}).  b305 puts the on-board structure OBJECT
 // back into the hand (cards/b305.py:40-45): such an entry aliases entity slot x while that entity is
 // on the board (CF_ALIAS) and keeps its last strength in x afterwards (CF_STR).  Both kinds have a
@@ -207,6 +214,7 @@ typedef uint32_t msb_u32x4 __attribute__((vector_size(16)));
 #if !defined(__HIPCC__)
 static thread_local int32_t* msb_trace_log = nullptr;   // {card, position} pairs (FlatMem::trace_ability)
 static thread_local int msb_trace_n = 0, msb_trace_cap = 0;
+static thread_local uint32_t msb_host_wk[512];   // SK_CAP words: the work stack of the game this thread is stepping
 #endif
 // Host / flat: the record is a contiguous byte array.
 struct FlatMem {
@@ -240,7 +248,14 @@ struct FlatMem {
   MSB_HD MSB_INL double ldfg(int g, int k) const { return ldf(g * 16 + k); }
   MSB_HD MSB_INL void stfg(int g, int k, double v) { stf(g * 16 + k, v); }
   MSB_HD MSB_INL static double wtab(int age) { return g_wtab.v[age & AGE_MAX]; }
-  MSB_HD MSB_INL static bool stack_ok() { return true; }   // the host stack is not a concern
+  // work stack: a per-thread array on the host; the device never steps a game through this accessor
+#if !defined(__HIPCC__)
+  MSB_HD MSB_INL static uint32_t sk_ld(int i) { return msb_host_wk[i]; }
+  MSB_HD MSB_INL static void sk_st(int i, uint32_t v) { msb_host_wk[i] = v; }
+#else
+  MSB_HD MSB_INL static uint32_t sk_ld(int) { return 0; }
+  MSB_HD MSB_INL static void sk_st(int, uint32_t) {}
+#endif
   // order in which abilities run (scenario tests): a log the host oracle can switch on; compiled out of device code
   MSB_HD MSB_INL static void trace_ability(int card, int pos) {
 #if !defined(__HIPCC__)
@@ -257,28 +272,6 @@ struct FlatMem {
 };
 
 #if defined(__HIPCC__)
-// Per-lane stack of the recursive rules core on the device (hipLimitStackSize, a device-wide setting the host raises to
-// at least this before every launch).  Measured frames (ISA of round 2): kernel 0.6-3.4 KB, move 128-192 B, run_ability
-// 80 B, a card's ability <= 272 B, s203 608 B: 40 nested levels stay below 10 KB on the standard record; the extended
-// records add the memory copies (rem_deep_copy x REM_DEPTH, a 2.5 KB stream regeneration).  stack_ok() turns an overrun
-// -- should one ever come close -- into FAULT_DEPTH instead of a write into the next wavefront's stack.
-#if defined(MSB_EXT) && MSB_EXT == 2
-constexpr int STACK_BYTES_MIN = 32768;
-#elif defined(MSB_EXT) && MSB_EXT
-constexpr int STACK_BYTES_MIN = 24576;
-#else
-constexpr int STACK_BYTES_MIN = 16384;   // 32 KiB on this record costs 6 % (fewer wavefronts get scratch), 24 KiB nothing
-#endif
-constexpr int STACK_GUARD = STACK_BYTES_MIN - 4096;   // deepest call chain below a check + the largest leaf frame
-MSB_HD MSB_INL bool device_stack_ok() {
-#if defined(__HIP_DEVICE_COMPILE__)
-  uint32_t sp;
-  asm volatile("s_mov_b32 %0, s32" : "=s"(sp));   // s32: the stack pointer of the AMDGPU calling convention, bytes per lane
-  return sp <= (uint32_t)STACK_GUARD;
-#else
-  return true;
-#endif
-}
 // Device-only forms with explicit address spaces, so that hipcc emits ds_read/ds_write (LDS) and
 // global_load/global_store (HBM) instead of flat_* instructions behind non-inlined calls.
 #define MSB_AS_LDS __attribute__((address_space(3)))
@@ -289,9 +282,12 @@ MSB_HD MSB_INL double lds_wtab(int age) {
   if (age < WT_LDS_N) return *(MSB_AS_LDS const double*)(uintptr_t)(WT_LDS + 8 * age);
   return g_wtab.v[age & AGE_MAX];
 }
-MSB_HD MSB_INL void lds_init_wtab() {   // call with all threads of the workgroup, before any engine code
+// call with all threads of the workgroup, before any engine code.  wk_ovf: this workgroup's overflow block of the work
+// stack (LANES * (SK_CAP - SKW) words, see LaneMem::sk_*), or null where no game is stepped
+MSB_HD MSB_INL void lds_init_wtab(uint32_t* wk_ovf = nullptr) {
   for (int i = (int)__builtin_amdgcn_workitem_id_x(); i < WT_LDS_N; i += (int)__builtin_amdgcn_workgroup_size_x())
     *(MSB_AS_LDS double*)(uintptr_t)(WT_LDS + 8 * i) = g_wtab.v[i];
+  if (__builtin_amdgcn_workitem_id_x() == 0) *(MSB_AS_LDS uint64_t*)(uintptr_t)WK_OVF_LDS = (uint64_t)(uintptr_t)wk_ovf;
   __syncthreads();
 }
 // LDS image of one record, interleaved across the lanes of a wave in 16-BYTE granules: granule c of
@@ -303,8 +299,24 @@ MSB_HD MSB_INL void lds_init_wtab() {   // call with all threads of the workgrou
 // BASE (a compile-time constant) and the lane is the work-item id.  An Engine over such an accessor is an
 // empty object -- nothing has to be reloaded through `this` behind the non-inlined (recursive) calls of
 // the rules core, which cost a flat_load round trip per call when the accessor held a pointer.
-template <int LANES, int BASE>
+//
+// SKB / SKW: LDS address and words per lane of the work stack's resident part, interleaved across the lanes word by word
+// (word i of lane l at SKB + (i*LANES + l)*4); words SKW.. of a lane live in the workgroup's overflow block in HBM
+// (word-major as well: lanes at the same depth touch neighbouring words).
+template <int LANES, int BASE, int SKB = 0, int SKW = 0>
 struct LaneMem {   // this lane's private record among LANES interleaved ones
+  MSB_HD MSB_INL static uint32_t* sk_ovf(int i) {
+    uint32_t* base = (uint32_t*)(uintptr_t)(*(MSB_AS_LDS const uint64_t*)(uintptr_t)WK_OVF_LDS);
+    return base + (size_t)(i - SKW) * LANES + (int)__builtin_amdgcn_workitem_id_x();
+  }
+  MSB_HD MSB_INL static uint32_t sk_ld(int i) {
+    if (i < SKW) return *(MSB_AS_LDS const uint32_t*)(uintptr_t)(SKB + (i * LANES + (int)__builtin_amdgcn_workitem_id_x()) * 4);
+    return *sk_ovf(i);
+  }
+  MSB_HD MSB_INL static void sk_st(int i, uint32_t v) {
+    if (i < SKW) *(MSB_AS_LDS uint32_t*)(uintptr_t)(SKB + (i * LANES + (int)__builtin_amdgcn_workitem_id_x()) * 4) = v;
+    else *sk_ovf(i) = v;
+  }
   MSB_HD MSB_INL static MSB_AS_LDS uint8_t* b(int o) {
     return (MSB_AS_LDS uint8_t*)(uintptr_t)(BASE + (o >> 4) * (LANES * 16) + (o & 15) + (int)__builtin_amdgcn_workitem_id_x() * 16);
   }
@@ -336,13 +348,12 @@ struct LaneMem {   // this lane's private record among LANES interleaved ones
   MSB_HD MSB_INL static double ldfg(int g, int k) { return *(MSB_AS_LDS const double*)gb(g, k); }
   MSB_HD MSB_INL static void stfg(int g, int k, double v) { *(MSB_AS_LDS double*)gb(g, k) = v; }
   MSB_HD MSB_INL static double wtab(int age) { return lds_wtab(age); }
-  MSB_HD MSB_INL static bool stack_ok() { return device_stack_ok(); }
   MSB_HD MSB_INL static void trace_ability(int, int) {}
 };
 // The same with the ability log of the scenario tests switched on: {card, position} pairs appended to an LDS array
 // (count at TRACE_BASE, pairs behind it).  Only the one-lane diagnostics kernel of monsoon_debug_op uses it.
-template <int LANES, int BASE, int TRACE_BASE, int TRACE_CAP>
-struct TraceLaneMem : LaneMem<LANES, BASE> {
+template <int LANES, int BASE, int SKB, int SKW, int TRACE_BASE, int TRACE_CAP>
+struct TraceLaneMem : LaneMem<LANES, BASE, SKB, SKW> {
   MSB_HD MSB_INL static void trace_ability(int card, int pos) {
     MSB_AS_LDS int32_t* t = (MSB_AS_LDS int32_t*)(uintptr_t)TRACE_BASE;
     int n = t[0];
@@ -379,8 +390,10 @@ struct SharedMem {   // one contiguous record read by every lane of the wave (LD
   MSB_HD MSB_INL static double ldfg(int g, int k) { return ldf(g * 16 + k); }
   MSB_HD MSB_INL static void stfg(int g, int k, double v) { stf(g * 16 + k, v); }
   MSB_HD MSB_INL static double wtab(int age) { return lds_wtab(age); }
-  MSB_HD MSB_INL static bool stack_ok() { return device_stack_ok(); }
   MSB_HD MSB_INL static void trace_ability(int, int) {}
+  // the shared copy is only read (legal mask, features): nothing is ever stepped through it
+  MSB_HD MSB_INL static uint32_t sk_ld(int) { return 0; }
+  MSB_HD MSB_INL static void sk_st(int, uint32_t) {}
 };
 #endif
 

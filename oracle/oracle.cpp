@@ -19,6 +19,17 @@
 #include <thread>
 #include <vector>
 
+// Two builds of this file (oracle/Makefile):
+//   liboracle*.so        the ORACLE: oracle/recursive/ -- the rules core written the way the reference is, as mutually
+//                        recursive functions (move -> ability -> damage -> destroy -> ability ...), host only;
+//   libproduct_host*.so  (-DORC_PRODUCT_CORE) the PRODUCT's rules core (monsoon_amd/csrc/rules.h: the explicit work
+//                        stack the HIP kernels run) compiled for the host, so that its semantics can be checked against
+//                        the golden vectors and against the oracle without a GPU.  Test infrastructure as well.
+#if defined(ORC_PRODUCT_CORE)
+#include "../monsoon_amd/csrc/rules.h"
+#else
+#include "recursive/rules.h"
+#endif
 #include "../monsoon_amd/csrc/canon.h"
 
 using namespace msb;
@@ -270,7 +281,7 @@ void orc_usage(void* h, int gi, int* out) {
 // monsoon_game_faults of the product: the fault that stopped the game, else the first capacity code a look-ahead hit
 int orc_game_fault(void* h, int gi) {
   Game& g = ((Oracle*)h)->games[gi];
-  return g.st[H_FAULT] ? g.st[H_FAULT] : g.la_fault;
+  return g.st[H_FAULT] >= FAULT_CAPACITY ? g.st[H_FAULT] : (g.la_fault ? g.la_fault : g.st[H_FAULT]);
 }
 
 // scores156: NaN for illegal actions.  Returns the chosen action.

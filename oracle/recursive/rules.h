@@ -7,9 +7,9 @@
 // turn-start movement iterates a snapshot of entity objects, and deferred triggers are a LIFO
 // stack with a non-counting re-entrancy latch.
 //
-// Control flow: the reference recurses (move -> ability -> deal_damage -> destroy -> ability -> command -> move ...).
-// Here every function on such a cycle is a FRAME on an explicit per-game work stack and Engine::run() is the only
-// loop (see "Control flow" below): no call cycle is left in the C++, so the device code needs no dynamic stack.
+// Control flow: the reference recurses (move -> ability -> deal_damage -> destroy -> ability ->
+// command -> move ...).  The recursion is kept (hipcc supports it on gfx950 with a dynamic
+// scratch stack); only the tail call at the end of the ability wrapper (card.py:54-60) is a loop.
 #pragma once
 #include "mt19937.h"
 #include "pyset.h"
@@ -185,10 +185,6 @@ constexpr int MAX_DEPTH = 40;
 // third batch (no gain, left out-of-line): shape_tiles +0.4 %, shuffle/sorted_head 0, legal_mask_v +0.2 %,
 // command/teleport/push_pull/force_attack/spawn/respawn +0.8 %; flip + to_next_turn inlined -8.5 %, ability_spell -18 %.
 // One non-inlined function per card instead of one switch function (abilities.inc): +3 %.
-// leaf card abilities: one non-inlined function each (a call from run(), no call inside)
-#ifndef MSB_A_CARD
-#define MSB_A_CARD MSB_NOINLINE
-#endif
 #ifndef MSB_A_TILES
 #define MSB_A_TILES MSB_NOINLINE
 #endif
@@ -658,6 +654,7 @@ struct Engine {
   }
   MSB_HD MSB_INL uint32_t empty_mask() const { return ~occ_mask() & 0xFFFFFu; }
   MSB_HD MSB_INL void begin_step() {
+    MSB_SCOPE(PS_BEGIN_STEP);
     // one shift per tile, no compare: an empty tile (0xFF) sets the top bit, which is not an entity slot
     static_assert((SLOT_NONE & 31) >= 28, "the empty marker must map outside the slot bits");
     Bits used = Bits::none();
@@ -701,10 +698,13 @@ struct Engine {
     m.st8(H_DEPTH, 0);
   }
   MSB_HD MSB_INL int new_entity(int card, int owner, int strength, int movement, bool ff) {
+    MSB_PRECALL();
     int r_ = new_entity_impl(card, owner, strength, movement, ff);
+    MSB_POSTCALL(PS_NEW_ENTITY);
     return r_;
   }
   MSB_HD MSB_A_NEWENT int new_entity_impl(int card, int owner, int strength, int movement, bool ff) {
+    MSB_SCOPE(PS_NEW_ENTITY);
     int e = alloc_entity();
     if (fault()) return e;
     // card | flags<<8 | pos<<16 | mov<<24 ; st0..st3 = 0 ; st4 = 0, move_id = 0, strength<<16 ; dmg = 0, path_n = 0
@@ -954,85 +954,38 @@ struct Engine {
     return w;
   }
   // copy.deepcopy of a memory list (the list object, its entities, their own memories, and -- through entity.player
-  // -- the world each of them belongs to, once per deepcopy call: memo[]).  The reference's recursion over nested
-  // memories is an explicit depth-first walk here (pre-order, so lists, slots and worlds are handed out in the same
-  // order): level L copies list s_src[L] into s_dst[L], s_k[L] is its next element and s_c[L] the copy whose own memory
-  // the level below is making.
-  MSB_HD MSB_NOINLINE int rem_deep_copy(int src0, int* memo, int root_old, int root_new) {
-    int s_src[REM_DEPTH + 2], s_dst[REM_DEPTH + 2], s_k[REM_DEPTH + 2], s_c[REM_DEPTH + 2];
-    int L = 0, ret = REM_NONE;
-    enum { CALL, LOOP, RET } mode = CALL;
-    s_src[0] = src0;
-    for (;;) {
-      if (mode == CALL) {   // deepcopy of list s_src[L] begins
-        const int src = s_src[L];
-        if (L > REM_DEPTH) {
-          set_fault(FAULT_CAP_REM);
-          ret = REM_NONE;
-          mode = RET;
-          continue;
-        }
-        if (src == REM_LOST) {
-          ret = REM_LOST;
-          mode = RET;
-          continue;
-        }
-        const int dst = rem_alloc_soft();
-        if (dst == REM_LOST) {   // no list storage: the copy's memory is lost unless it is never used
-          ret = REM_LOST;
-          mode = RET;
-          continue;
-        }
-        m.st8(rem_off(dst), rem_n(src));
-        s_dst[L] = dst;
-        s_k[L] = 0;
-        mode = LOOP;
-      } else if (mode == LOOP) {   // next element of the list being copied at level L
-        const int src = s_src[L], dst = s_dst[L], k = s_k[L];
-        if (k >= rem_n(src) || fault()) {
-          ret = dst;
-          mode = RET;
-          continue;
-        }
-        const int r = rem_get(src, k);
-        const int c = dup_entity(r);
-        if (fault()) {
-          ret = dst;
-          mode = RET;
-          continue;
-        }
-        m.st8(rem_off(dst) + 4 + k, c);
-        const int H = m.ld8(E_HOME + r) & 0x7f;
-        int nh = WORLD_LOST;
-        if (H != WORLD_LOST) {
-          if (memo[H] < 0) memo[H] = world_snapshot(H, root_old, root_new);
-          if (fault()) {
-            ret = dst;
-            mode = RET;
-            continue;
-          }
-          nh = memo[H];
-        }
-        m.st8(E_HOME + c, nh);
-        s_k[L] = k + 1;
-        const int L2 = m.ld8(E_REM + r);
-        if (L2 == REM_LOST || (L2 != REM_NONE && rem_n(L2) > 0)) {
-          s_c[L] = c;
-          L++;
-          s_src[L] = L2;
-          mode = CALL;
-        }
-      } else {   // level L is done: `ret` is its copy
-        if (L == 0) return ret;
-        L--;
-        if (fault()) {   // the level above breaks out of its loop and hands back what it has
-          ret = s_dst[L];
-          continue;
-        }
-        m.st8(E_REM + s_c[L], ret);
-        mode = LOOP;
+  // -- the world each of them belongs to, once per deepcopy call: memo[])
+  MSB_HD int rem_deep_copy(int src, int* memo, int root_old, int root_new, int depth) {
+    if (depth > REM_DEPTH) {
+      set_fault(FAULT_CAP_REM);
+      return REM_NONE;
+    }
+    if (src == REM_LOST) return REM_LOST;
+    int dst = rem_alloc_soft();
+    if (dst == REM_LOST) return REM_LOST;   // no list storage: the copy's memory is lost unless it is never used
+    int n = rem_n(src);
+    m.st8(rem_off(dst), n);
+    for (int k = 0; k < n && !fault(); k++) {
+      int r = rem_get(src, k);
+      int c = dup_entity(r);
+      if (fault()) break;
+      m.st8(rem_off(dst) + 4 + k, c);
+      int H = m.ld8(E_HOME + r) & 0x7f;
+      int nh = WORLD_LOST;
+      if (H != WORLD_LOST) {
+        if (memo[H] < 0) memo[H] = world_snapshot(H, root_old, root_new);
+        if (fault()) break;
+        nh = memo[H];
+      }
+      m.st8(E_HOME + c, nh);
+      int L2 = m.ld8(E_REM + r);
+      if (L2 == REM_LOST || (L2 != REM_NONE && rem_n(L2) > 0)) {
+        int d2 = rem_deep_copy(L2, memo, root_old, root_new, depth + 1);
+        if (fault()) break;
+        m.st8(E_REM + c, d2);
       }
     }
+    return dst;
   }
   // Card.copy() of the on-board entity e (card.py:71-75): deepcopy, then copied.player = self.player
   MSB_HD MSB_NOINLINE int rem_copy_entity(int e) {
@@ -1044,17 +997,17 @@ struct Engine {
     } else if (L != REM_NONE && rem_n(L) > 0) {
       int memo[WORLD_CAP + 1];
       for (int i = 0; i <= WORLD_CAP; i++) memo[i] = -1;
-      int d = rem_deep_copy(L, memo, e, c);
+      int d = rem_deep_copy(L, memo, e, c, 0);
       if (fault()) return c;
       m.st8(E_REM + c, d);
     }
     return c;
   }
 
-
   // Board.calculate_front_line, board.py:78-92.  `player` is an order; the reference compares
   // Player objects by order (player.py:39-40).
   MSB_HD MSB_A_FRONT void calculate_front_line(int player) {
+    MSB_SCOPE(PS_FRONT_LINE);
     // any(board[y][x] is not None and board[y][x].player == player for x in range(4)) per row: the first
     // (local: lowest y, remote: highest y) row holding one of the player's entities; only occupied tiles are read
     const uint32_t r0 = board_row(0), r1 = board_row(1), r2 = board_row(2), r3 = board_row(3), r4 = board_row(4);
@@ -1086,10 +1039,13 @@ struct Engine {
 
   // Board.get_targets, board.py:147-204
   MSB_HD MSB_INL PList get_targets(int pov, Tgt t, int exclude_pk) {
+    MSB_PRECALL();
     PList r_ = get_targets_impl(pov, t, exclude_pk);
+    MSB_POSTCALL(PS_GET_TARGETS);
     return r_;
   }
   MSB_HD MSB_A_TARGETS PList get_targets_impl(int pov, Tgt t, int exclude_pk) {
+    MSB_SCOPE(PS_GET_TARGETS);
     PList out;
     out.clear();
     const bool asc = (pov == local());
@@ -1182,6 +1138,7 @@ struct Engine {
   }
   // get_front_tiles .. get_surrounding_tiles WITHOUT a target: fixed enumeration order.
   MSB_HD MSB_A_TILES PList shape_tiles(int shape, P c, int pov) {
+    MSB_SCOPE(PS_SHAPE_TILES);
     PList out;
     out.clear();
     switch (shape) {
@@ -1235,6 +1192,7 @@ struct Engine {
   }
   // ... WITH a target: get_targets order filtered by membership; front/behind re-sorted by y.
   MSB_HD MSB_A_SHAPE PList shape_targets(int shape, P c, int pov, Tgt t, int exclude_pk) {
+    MSB_SCOPE(PS_SHAPE_TARGETS);
     PList all = get_targets(pov, t, exclude_pk);
     PList out;
     out.clear();
@@ -1267,6 +1225,7 @@ struct Engine {
   MSB_HD MSB_INL int choice_index(int n) { return rng_randint(0, n); }
   MSB_HD MSB_INL P choice_point(PList l) { return l.at(choice_index(l.n())); }
   MSB_HD MSB_A_SHUFFLE PList shuffle(PList l) {
+    MSB_SCOPE(PS_SHUFFLE);
     for (int i = l.n() - 1; i >= 1; i--) {
       int j = (int)rng_interval((uint32_t)i);
       int tmp = l.get(i);
@@ -1280,6 +1239,7 @@ struct Engine {
   // BEFORE sorting; the sort is stable and reverse keeps ties in order, so the first k of the sorted
   // list are the k best under (key, r) with earlier elements winning ties.  key_mode: 0 = y, 1 = strength.
   MSB_HD MSB_A_SHUFFLE PList sorted_head(PList l, int key_mode, bool rev, int k) {
+    MSB_SCOPE(PS_SORTED_HEAD);
     int b0 = -1, b1 = -1, k0 = 0, k1 = 0;
     double r0 = 0.0, r1 = 0.0;
     int m = l.n();
@@ -1307,61 +1267,6 @@ struct Engine {
   }
 
   // ------------------------------------------------------------------------------------------
-  // Control flow: an explicit work stack instead of the reference's recursion
-  // ------------------------------------------------------------------------------------------
-  // The reference recurses: Unit.move -> activate_ability -> deal_damage -> destroy -> pop_trigger -> activate_ability
-  // -> command -> move ... (unit.py:124-231, card.py:48-62, board.py:46-56).  Here every function on such a cycle is a
-  // FRAME on the game's work stack (M::sk_ld / sk_st: on the device LDS words next to the record, state.h) and run()
-  // is the only loop: it takes the top frame and executes its handler until the handler "calls" -- pushes the callee's
-  // frame and returns to run() -- or finishes and pops itself.  A handler is a forward-only state machine: the
-  // frame's `state` says where to resume, and a backward jump (the next round of a loop whose body calls) goes through
-  // run().  A call that completes without pushing anything (damage that kills nobody and fires nothing) continues
-  // inline.  A fault ends the step at once, like the exception it stands for (run() drops the stack).
-  //   frame = header word on top {fn, state, a, b: one byte each} + the frame's other words below it
-  //   call_X(k, ...): the part of X before its first nested call runs at once, in the caller; what is left of X, if
-  //   anything, waits in a frame.  The caller tells "completed" from "pending" by the stack pointer.
-  struct Wk {
-    int sp;       // words in use on this game's work stack
-    int result;   // Stormbound.step's reward | done << 1
-  };
-  enum : int { F_STEP = 1, F_UNIT_PLAY, F_MOVE, F_RUNAB, F_CTXLEAVE, F_DESTROY_TAIL, F_CMD_TAIL, F_EACH, F_AFTER, F_TURN };
-  MSB_HD MSB_INL static uint32_t mk_hdr(int fn, int st, int a, int b) {
-    return (uint32_t)(fn & 0xff) | ((uint32_t)(st & 0xff) << 8) | ((uint32_t)(a & 0xff) << 16) | ((uint32_t)(b & 0xff) << 24);
-  }
-  MSB_HD MSB_INL static int hdr_fn(uint32_t h) { return (int)(h & 0xff); }
-  MSB_HD MSB_INL static int hdr_st(uint32_t h) { return (int)((h >> 8) & 0xff); }
-  MSB_HD MSB_INL static int hdr_a(uint32_t h) { return (int)((h >> 16) & 0xff); }
-  MSB_HD MSB_INL static int hdr_b(uint32_t h) { return (int)(h >> 24); }
-  MSB_HD MSB_INL void wk_push(Wk& k, uint32_t v) {
-    m.sk_st(k.sp, v);
-    k.sp++;
-  }
-  // a point / slot list as six stack words (the three 64-bit lanes of a PList; the length travels in the frame)
-  MSB_HD MSB_INL void wk_push_list(Wk& k, const PList& l) {
-    for (int j = 2; j >= 0; j--) {
-      wk_push(k, (uint32_t)(l.w[j] >> 32));
-      wk_push(k, (uint32_t)l.w[j]);
-    }
-  }
-  MSB_HD MSB_INL PList wk_list(int first, int n) {   // `first` = stack index of the word pushed last (low half of lane 0)
-    PList l;
-    for (int j = 0; j < 3; j++)
-      l.w[j] = (unsigned long long)m.sk_ld(first - 2 * j) | ((unsigned long long)m.sk_ld(first - 2 * j - 1) << 32);
-    l.set_n(n);
-    return l;
-  }
-  MSB_HD MSB_INL void wk_store_list(int first, const PList& l) {
-    for (int j = 0; j < 3; j++) {
-      m.sk_st(first - 2 * j, (uint32_t)l.w[j]);
-      m.sk_st(first - 2 * j - 1, (uint32_t)(l.w[j] >> 32));
-    }
-  }
-  // ctx_leave(saved) once everything pushed after it has run: the tail of an entity method that switched worlds
-  MSB_HD MSB_INL void wk_push_ctx(Wk& k, int sv) {
-    if (REM_LISTS && sv >= 0) wk_push(k, mk_hdr(F_CTXLEAVE, 0, sv, 0));
-  }
-
-  // ------------------------------------------------------------------------------------------
   // Deferred triggers: Board.push_trigger / pop_trigger (board.py:46-56) and the wrapper that
   // Card.__init_subclass__ puts around every overridden activate_ability (card.py:48-62).
   // ------------------------------------------------------------------------------------------
@@ -1386,71 +1291,56 @@ struct Engine {
   }
   MSB_HD MSB_INL int trig_slot(int i) const { return m.ld8(OFF_TRIG + i) & TRIG_SLOT; }
   MSB_HD MSB_INL bool trig_src(int i) const { return TRIG_WIDE ? ((m.ld32(X_TRIGSRC) >> i) & 1u) != 0 : (m.ld8(OFF_TRIG + i) & 0x80) != 0; }
-  MSB_HD MSB_INL void call_pop_trigger(Wk& k) {
+  MSB_HD MSB_INL void pop_trigger() {
     int n = m.ld8(H_TRIG_N);
     if (n == 0 || m.ld8(H_RESOLVING)) return;
     int e = trig_slot(n - 1);
     bool src = trig_src(n - 1);
     m.st8(H_TRIG_N, n - 1);
-    call_run_ability(k, e, -1, PK_NONE, src);
+    run_ability(e, -1, PK_NONE, src);
   }
-  // wrapped activate_ability (card.py:48-62).  e >= 0: entity slot; e < 0: a spell, `spell` = card | owner << 8.
-  // Frame F_RUNAB {hdr: state, e (0xFF = a spell), recursion depth outside | src << 7; w1: spell | pos_pk << 16}:
-  // state 0 = the ability has yet to start, 1 = it has returned.  The ability itself starts on run()'s next turn, so
-  // that the card code exists once, in the handler.
-  MSB_HD MSB_INL void call_run_ability(Wk& k, int e, int spell, int pos_pk, bool src) {
+  // wrapped activate_ability.  subj >= 0: entity slot.  subj < 0: a spell, spell_card/spell_owner
+  // passed in `spell`.  The trailing pop_trigger() is a tail call in the reference, hence a loop.
+  MSB_HD MSB_INL void run_ability(int e, int spell, int pos_pk, bool src) {
+    MSB_PRECALL();
     const int sv = e >= 0 ? ctx_enter(e) : -1;   // the wrapper works on self.player.board (card.py:54-60)
-    if (fault()) return;
-    wk_push_ctx(k, sv);
-    const int d = m.ld8(H_DEPTH);
-    if (d >= MAX_DEPTH || k.sp > SK_CAP - SK_MARGIN) {
+    run_ability_impl(e, spell, pos_pk, src);
+    ctx_leave(sv);
+    MSB_POSTCALL(PS_RUN_ABILITY);
+  }
+  MSB_HD MSB_NOINLINE void run_ability_impl(int e, int spell, int pos_pk, bool src) {
+    MSB_SCOPE(PS_RUN_ABILITY);
+    int d = m.ld8(H_DEPTH);
+    if (d >= MAX_DEPTH) {
       set_fault(FAULT_DEPTH);
       return;
     }
     m.st8(H_DEPTH, d + 1);
-    wk_push(k, (uint32_t)(spell & 0xffff) | ((uint32_t)(pos_pk & 0xff) << 16));
-    wk_push(k, mk_hdr(F_RUNAB, 0, e, d | (src ? 0x80 : 0)));
-  }
-  MSB_HD MSB_INL void h_runab(Wk& k, const uint32_t hdr) {
-    const int top = k.sp - 1;
-    const int d = hdr_b(hdr) & 0x7f;
-    if (hdr_st(hdr) == 0) {
-      const int e = hdr_a(hdr);
-      const bool src = (hdr_b(hdr) & 0x80) != 0;
-      const uint32_t w1 = m.sk_ld(top - 1);
-      const int pos_pk = (int)((w1 >> 16) & 0xff);
+    for (;;) {
       m.st8(H_RESOLVING, 1);
-      m.sk_st(top, hdr | (1u << 8));   // whatever the ability pushes, this frame resumes behind it
-      if (e != 0xff) {
-        M::trace_ability(e_card(e), m.ld8g(eg(e), EO_POS));   // diagnostics hook: nothing in the product
-        ability_entity(k, e, pos_pk, src);
-      } else {
-        const int spell = (int)(w1 & 0xffff);
-        M::trace_ability(spell & 0xff, -1);
-        ability_spell(k, spell & 0xff, spell >> 8, pos_pk);
-      }
-      if (fault() || k.sp - 1 != top) return;   // raised, or still running (its frames are above this one)
+      M::trace_ability(e >= 0 ? e_card(e) : (spell & 0xff), e >= 0 ? m.ld8g(eg(e), EO_POS) : -1);   // diagnostics hook: nothing in the product
+      if (e >= 0) {
+        MSB_PRECALL();
+        ability_entity(e, pos_pk, src);
+        MSB_POSTCALL(PS_ABILITY_ENTITY);
+      } else
+        ability_spell(spell & 0xff, spell >> 8, pos_pk);
+      if (fault()) break;
+      m.st8(H_RESOLVING, 0);
+      int n = m.ld8(H_TRIG_N);
+      if (n == 0) break;
+      e = trig_slot(n - 1);
+      src = trig_src(n - 1);
+      m.st8(H_TRIG_N, n - 1);
+      spell = -1;
+      pos_pk = PK_NONE;
     }
-    // the ability has returned, card.py:54-60
-    m.st8(H_RESOLVING, 0);
-    const int n = m.ld8(H_TRIG_N);
-    if (n == 0) {
-      m.st8(H_DEPTH, d);
-      k.sp = top - 1;
-      return;
-    }
-    // the wrapper's trailing pop_trigger() is a tail call in the reference: this frame runs the next deferred ability
-    const int e = trig_slot(n - 1);
-    const bool src = trig_src(n - 1);
-    m.st8(H_TRIG_N, n - 1);
-    m.sk_st(top - 1, 0xffffu | ((uint32_t)PK_NONE << 16));
-    m.sk_st(top, mk_hdr(F_RUNAB, 0, e, d | (src ? 0x80 : 0)));
+    m.st8(H_DEPTH, d);
   }
   // entity.activate_ability(...) as called by the engine: wrapped iff the class overrides it.
-  MSB_HD MSB_INL void call_activate(Wk& k, int e, int pos_pk, bool src) {
-    if (e_has_ability(e)) call_run_ability(k, e, -1, pos_pk, src);
+  MSB_HD MSB_INL void activate(int e, int pos_pk, bool src) {
+    if (e_has_ability(e)) run_ability(e, -1, pos_pk, src);
   }
-
 
   // ------------------------------------------------------------------------------------------
   // Damage / death / statuses
@@ -1462,36 +1352,38 @@ struct Engine {
   }
   MSB_HD MSB_INL void player_heal(int order, int amount) { set_pl_base(order, pl_base(order) + amount); }
 
-  // Unit.deal_damage unit.py:205-219 / Structure.deal_damage structure.py:52-63.  The reference returns the amount
-  // dealt; the one caller that uses it (cards/u405.py) takes min(amount, strength) itself (EACH_DMG_HEAL).
-  MSB_HD MSB_INL void call_entity_damage(Wk& k, int e, int amount, bool pending, bool src) {
+  // Unit.deal_damage unit.py:205-219 / Structure.deal_damage structure.py:52-63
+  MSB_HD MSB_INL int entity_deal_damage(int e, int amount, bool pending, bool src) {
+    MSB_PRECALL();
     const int sv = ctx_enter(e);
-    if (fault()) return;
-    wk_push_ctx(k, sv);
+    int r_ = entity_deal_damage_impl(e, amount, pending, src);
+    ctx_leave(sv);
+    MSB_POSTCALL(PS_DEAL_DAMAGE);
+    return r_;
+  }
+  MSB_HD MSB_A_DAMAGE int entity_deal_damage_impl(int e, int amount, bool pending, bool src) {
+    MSB_SCOPE(PS_DEAL_DAMAGE);
     int s = e_str(e);
     if (s - amount < 0) amount = s;
     e_set_dmg(e, amount);
     s -= amount;
     e_set_str(e, s);
     if (!pending && s <= 0) {
-      call_destroy(k, e, src);
+      destroy(e, src);
     } else if (e_trigger(e) == TR_AFTER_SURVIVING && s > 0) {
       push_trigger(e, src);
-      if (fault()) return;
-      call_pop_trigger(k);
+      pop_trigger();
     }
+    return amount;
   }
   // X.deal_damage(amount, source=...) where X = board.at(point): unit, structure or Player
-  MSB_HD MSB_INL void call_damage(Wk& k, int who, int amount, bool src) {
-    if (who >= AT_PLAYER) {
-      player_deal_damage(who - AT_PLAYER, amount);
-      return;
-    }
+  MSB_HD MSB_INL int deal_damage(int who, int amount, bool src) {
+    if (who >= AT_PLAYER) return player_deal_damage(who - AT_PLAYER, amount);
     if (who < 0) {
       set_fault(FAULT_PY_EXCEPTION);  // None.deal_damage
-      return;
+      return 0;
     }
-    call_entity_damage(k, who, amount, false, src);
+    return entity_deal_damage(who, amount, false, src);
   }
   MSB_HD MSB_INL void heal(int who, int amount) {
     if (who >= AT_PLAYER)
@@ -1501,25 +1393,25 @@ struct Engine {
     else
       e_set_str(who, e_str(who) + amount);
   }
-  // Unit.destroy unit.py:221-231 / Structure.destroy structure.py:65-69.  Frame F_DESTROY_TAIL: what a unit's destroy
-  // does once its ON_DEATH ability has returned.
-  MSB_HD MSB_INL void call_destroy(Wk& k, int e, bool src) {
+  // Unit.destroy unit.py:221-231 / Structure.destroy structure.py:65-69
+  MSB_HD MSB_INL void destroy(int e, bool src) {
+    MSB_PRECALL();
     const int sv = ctx_enter(e);
-    if (fault()) return;
-    wk_push_ctx(k, sv);
+    destroy_impl(e, src);
+    ctx_leave(sv);
+    MSB_POSTCALL(PS_DESTROY);
+  }
+  MSB_HD MSB_A_DESTROY void destroy_impl(int e, bool src) {
+    MSB_SCOPE(PS_DESTROY);
     if (e_is_unit(e)) {
       board_set(e_pos(e), -1);
       m.st8g(eg(e), EO_PATHN, 0);
       e_set_dmg(e, e_str(e));
       if (e_card_trigger(e) == TR_ON_DEATH) {
         push_trigger(e, src);
-        if (fault()) return;
-        if (!m.ld8(H_RESOLVING)) {   // pop_trigger() runs an ability now: the rest of destroy waits for it
-          wk_push(k, mk_hdr(F_DESTROY_TAIL, 0, 0, 0));
-          call_pop_trigger(k);
-          return;
-        }
+        pop_trigger();
       }
+      if (fault()) return;
       recalc_front_after_destroy();
     } else {
       e_set_dmg(e, e_str(e));
@@ -1563,11 +1455,14 @@ struct Engine {
   // ------------------------------------------------------------------------------------------
   // Unit.set_path, unit.py:78-122
   MSB_HD MSB_INL void set_path(int e, bool on_play) {
+    MSB_PRECALL();
     const int sv = ctx_enter(e);
     set_path_impl(e, on_play);
     ctx_leave(sv);
+    MSB_POSTCALL(PS_SET_PATH);
   }
   MSB_HD MSB_A_SETPATH void set_path_impl(int e, bool on_play) {
+    MSB_SCOPE(PS_SET_PATH);
     P position = e_pos(e);
     int confused_cached = e_st(e, ST_CONFUSED);
     int owner = e_owner(e);
@@ -1634,207 +1529,108 @@ struct Engine {
     m.st8g(eg(e), EO_PATHN, n);
   }
 
-  // Unit.move, unit.py:124-203.  Frame F_MOVE {hdr: state, e, recursion depth outside; w1: the path list bound when
-  // the loop started (fact #5); w2: i | n << 3 | move_id << 8 | target << 16 | flags << 24 (1 is_attacked,
-  // 2 target_pending, 4 local_pending); w3: the target's strength before the fight}.  The states are the places where
-  // the reference's move() is waiting for a nested call.
-  enum : int { MV_ENTRY = 0, MV_POISONED, MV_BEFORE_MOVING, MV_STEP, MV_BASE_HIT, MV_FIGHT, MV_STRUCK, MV_STRUCK_BACK,
-               MV_TARGET_DEAD, MV_SELF_DEAD, MV_AFTER_ATTACK, MV_DONE };
-  MSB_HD MSB_INL void call_move(Wk& k, int e) {
+  // Unit.move, unit.py:124-203
+  MSB_HD MSB_INL void move(int e) {
+    MSB_PRECALL();
     const int sv = ctx_enter(e);
-    if (fault()) return;
-    wk_push_ctx(k, sv);
-    const int d = m.ld8(H_DEPTH);
-    if (d >= MAX_DEPTH || k.sp > SK_CAP - SK_MARGIN) {
+    move_impl(e);
+    ctx_leave(sv);
+    MSB_POSTCALL(PS_MOVE);
+  }
+  MSB_HD MSB_NOINLINE void move_impl(int e) {
+    MSB_SCOPE(PS_MOVE);
+    int d = m.ld8(H_DEPTH);
+    if (d >= MAX_DEPTH) {
       set_fault(FAULT_DEPTH);
       return;
     }
     m.st8(H_DEPTH, d + 1);
-    wk_push(k, 0);
-    wk_push(k, 0);
-    wk_push(k, 0);
-    wk_push(k, mk_hdr(F_MOVE, MV_ENTRY, e, d));
-  }
-  MSB_HD MSB_INL void h_move(Wk& k, const uint32_t hdr) {
-    const int top = k.sp - 1;
-    const int e = hdr_a(hdr), d = hdr_b(hdr);
-    uint32_t path = m.sk_ld(top - 1);
-    const uint32_t w2 = m.sk_ld(top - 2);
-    int i = (int)(w2 & 7), n = (int)((w2 >> 3) & 7), current_id = (int)((w2 >> 8) & 0xff), target = (int)((w2 >> 16) & 0xff);
-    int flags = (int)(w2 >> 24);
-    int cached = (int)(int16_t)(m.sk_ld(top - 3) & 0xffffu);
-    const int trig = e_trigger(e);
-    int next = MV_DONE;
-    P dest{0, 0};
-    int owner = 0, tp = 0;
-#define MV_WAIT(s_)  \
-  do {               \
-    next = (s_);     \
-    goto wait;       \
-  } while (0)
-#define MV_CALLED(s_)                        \
-  do {                                       \
-    if (fault()) return;                     \
-    if (k.sp - 1 != top) MV_WAIT(s_);        \
-  } while (0)
-    switch (hdr_st(hdr)) {
-      case MV_ENTRY:
-        current_id = (m.ld8g(eg(e), EO_MOVEID) + 1) & 0xff;
-        m.st8g(eg(e), EO_MOVEID, current_id);
-        if (phase() == PH_TURN_START) {
-          if (e_st(e, ST_POISONED) > 0) {
-            call_entity_damage(k, e, 1, false, false);
-            MV_CALLED(MV_POISONED);
-          } else if (e_st(e, ST_VITALIZED) > 0)
-            e_set_str(e, e_str(e) + 1);
-        }
-        // fall through
-      case MV_POISONED:
-        if (phase() == PH_TURN_START && e_frozen(e)) {
-          e_st_remove(e, ST_FROZEN);
-          goto done;
-        }
-        if (m.ld8g(eg(e), EO_PATHN) == 0) goto done;
-        if (trig == TR_BEFORE_MOVING && !e_disabled(e)) {
-          call_run_ability(k, e, -1, PK_NONE, true);
-          if (fault()) return;
-          MV_WAIT(MV_BEFORE_MOVING);
-        }
-        // fall through
-      case MV_BEFORE_MOVING:
-        if (e_frozen(e)) goto done;
-        // `for destination in self.path` iterates the list object bound now (fact #5)
-        n = m.ld8g(eg(e), EO_PATHN);
-        path = e_path(e);
-        i = 0;
-        // fall through
-      case MV_STEP:
-        if (i >= n) goto done;
-        dest = p_unpack((path >> (8 * i)) & 0xff);
-        owner = e_owner(e);  // self.player is re-read by the reference; convert() may change it
-        flags = 0;
-        if (dest.y < 0 || dest.y > 4) {
-          if (trig == TR_BEFORE_ATTACKING && !e_disabled(e)) {
-            call_run_ability(k, e, -1, p_pack(dest), true);
-            if (fault()) return;
-            MV_WAIT(MV_BASE_HIT);
-          }
-          goto base_hit;
-        }
-        target = at(dest);
-        if (target != AT_NONE && e_owner(target) == owner && dest.x == e_pos(e).x) goto done;
-        if (!(target != AT_NONE && (e_confused(e) || e_owner(target) != owner))) goto advance;
-        if (trig == TR_BEFORE_ATTACKING && !e_disabled(e)) {
-          call_run_ability(k, e, -1, p_pack(dest), true);
-          if (fault()) return;
-          MV_WAIT(MV_FIGHT);
-        }
-        goto fight;
-      case MV_BASE_HIT:
-        dest = p_unpack((path >> (8 * i)) & 0xff);
-      base_hit:
-        tp = dest.y < 0 ? remote() : local();
-        player_deal_damage(tp, e_str(e));
-        if (pl_base(tp) > 0) {
-          call_destroy(k, e, false);
-          MV_CALLED(MV_DONE);
-        }
-        goto done;
-      case MV_FIGHT:
-        dest = p_unpack((path >> (8 * i)) & 0xff);
-      fight:
-        target = at(dest);
-        if (target == AT_NONE) goto advance;
-        cached = e_str(target);   // target_strength_cached
-        flags = ((e_trigger(target) == TR_ON_DEATH && !e_disabled(target)) ? 2 : 0) | ((trig == TR_ON_DEATH && !e_disabled(e)) ? 4 : 0);
-        call_entity_damage(k, target, e_str(e), (flags & 2) != 0, false);
-        MV_CALLED(MV_STRUCK);
-        // fall through
-      case MV_STRUCK:
-        call_entity_damage(k, e, cached, (flags & 4) != 0, false);
-        MV_CALLED(MV_STRUCK_BACK);
-        // fall through
-      case MV_STRUCK_BACK:
-        if (e_str(target) <= 0 && (flags & 2)) {
-          call_destroy(k, target, false);
-          MV_CALLED(MV_TARGET_DEAD);
-        }
-        // fall through
-      case MV_TARGET_DEAD:
-        if (e_str(e) <= 0 && (flags & 4)) {
-          call_destroy(k, e, false);
-          MV_CALLED(MV_SELF_DEAD);
-        }
-        // fall through
-      case MV_SELF_DEAD:
-        flags |= 1;   // is_attacked
-      advance:
-        dest = p_unpack((path >> (8 * i)) & 0xff);
-        if (current_id != m.ld8g(eg(e), EO_MOVEID)) goto done;
-        if (at(dest) == AT_NONE && e_str(e) > 0) {
-          board_set(e_pos(e), -1);
-          board_set(dest, e);
-          const int o = e_owner(e);
-          if (pl_front(o) > dest.y) set_pl_front(o, dest.y > 1 ? dest.y : 1);
-          if ((flags & 1) && trig == TR_AFTER_ATTACKING && !e_disabled(e)) {
-            call_run_ability(k, e, -1, PK_NONE, true);
-            if (fault()) return;
-            MV_WAIT(MV_AFTER_ATTACK);
-          }
-          if (e_confused(e)) e_st_remove(e, ST_CONFUSED);
-        }
-        goto next_step;
-      case MV_AFTER_ATTACK:
-        if (e_confused(e)) e_st_remove(e, ST_CONFUSED);
-      next_step:
-        i++;
-        if (i < n) MV_WAIT(MV_STEP);   // the next destination: a backward jump, through run()
-        goto done;
-      default:   // MV_DONE
-        break;
-    }
-  done:
+    move_body(e);
     m.st8(H_DEPTH, d);
-    k.sp = top - 3;
-    return;
-  wait:
-    m.sk_st(top - 1, path);
-    m.sk_st(top - 2, (uint32_t)(i & 7) | ((uint32_t)(n & 7) << 3) | ((uint32_t)(current_id & 0xff) << 8) | ((uint32_t)(target & 0xff) << 16) |
-                         ((uint32_t)(flags & 0xff) << 24));
-    m.sk_st(top - 3, (uint32_t)(cached & 0xffff));
-    m.sk_st(top, mk_hdr(F_MOVE, next, e, d));
-#undef MV_WAIT
-#undef MV_CALLED
+  }
+  MSB_HD MSB_INL void move_body(int e) {
+    int current_id = (m.ld8g(eg(e), EO_MOVEID) + 1) & 0xff;
+    m.st8g(eg(e), EO_MOVEID, current_id);
+    if (phase() == PH_TURN_START) {
+      if (e_st(e, ST_POISONED) > 0)
+        entity_deal_damage(e, 1, false, false);
+      else if (e_st(e, ST_VITALIZED) > 0)
+        e_set_str(e, e_str(e) + 1);
+      if (fault()) return;
+      if (e_frozen(e)) {
+        e_st_remove(e, ST_FROZEN);
+        return;
+      }
+    }
+    if (m.ld8g(eg(e), EO_PATHN) == 0) return;
+    int trig = e_trigger(e);
+    if (trig == TR_BEFORE_MOVING && !e_disabled(e)) run_ability(e, -1, PK_NONE, true);
+    if (fault()) return;
+    if (e_frozen(e)) return;
+    // `for destination in self.path` iterates the list object bound now (fact #5)
+    int n = m.ld8g(eg(e), EO_PATHN);
+    uint32_t path = e_path(e);
+    int owner = e_owner(e);  // self.player is re-read by the reference; convert() may change it
+    for (int i = 0; i < n; i++) {
+      P dest = p_unpack((path >> (8 * i)) & 0xff);
+      owner = e_owner(e);
+      if (dest.y < 0 || dest.y > 4) {
+        if (trig == TR_BEFORE_ATTACKING && !e_disabled(e)) run_ability(e, -1, p_pack(dest), true);
+        if (fault()) return;
+        int target = dest.y < 0 ? remote() : local();
+        player_deal_damage(target, e_str(e));
+        if (pl_base(target) > 0) destroy(e, false);
+        return;
+      }
+      int target = at(dest);
+      bool is_attacked = false;
+      if (target != AT_NONE && e_owner(target) == owner && dest.x == e_pos(e).x) return;
+      if (target != AT_NONE && (e_confused(e) || e_owner(target) != owner)) {
+        if (trig == TR_BEFORE_ATTACKING && !e_disabled(e)) run_ability(e, -1, p_pack(dest), true);
+        if (fault()) return;
+        target = at(dest);
+        if (target != AT_NONE) {
+          int target_strength_cached = e_str(target);
+          bool target_pending = e_trigger(target) == TR_ON_DEATH && !e_disabled(target);
+          bool local_pending = trig == TR_ON_DEATH && !e_disabled(e);
+          entity_deal_damage(target, e_str(e), target_pending, false);
+          if (fault()) return;
+          entity_deal_damage(e, target_strength_cached, local_pending, false);
+          if (fault()) return;
+          if (e_str(target) <= 0 && target_pending) destroy(target, false);
+          if (fault()) return;
+          if (e_str(e) <= 0 && local_pending) destroy(e, false);
+          if (fault()) return;
+          is_attacked = true;
+        }
+      }
+      if (current_id != m.ld8g(eg(e), EO_MOVEID)) return;
+      if (at(dest) == AT_NONE && e_str(e) > 0) {
+        board_set(e_pos(e), -1);
+        board_set(dest, e);
+        int o = e_owner(e);
+        if (pl_front(o) > dest.y) set_pl_front(o, dest.y > 1 ? dest.y : 1);
+        if (is_attacked && trig == TR_AFTER_ATTACKING && !e_disabled(e)) run_ability(e, -1, PK_NONE, true);
+        if (fault()) return;
+        if (e_confused(e)) e_st_remove(e, ST_CONFUSED);
+      }
+    }
   }
 
-  // Unit.play, unit.py:66-76.  Frame F_UNIT_PLAY {hdr: state, e}: state 0 = the ON_PLAY ability has returned, 1 = move() has.
-  MSB_HD MSB_INL void call_unit_play(Wk& k, int e, P position) {
+  // Unit.play, unit.py:66-76
+  MSB_HD MSB_INL void unit_play(int e, P position) {
     e_set_flag(e, EF_RESOLVING_PLAY, true);
     board_set(position, e);
     set_path(e, true);
+    if (e_card_trigger(e) == TR_ON_PLAY) run_ability(e, -1, PK_NONE, true);
     if (fault()) return;
-    if (e_card_trigger(e) == TR_ON_PLAY) {
-      wk_push(k, mk_hdr(F_UNIT_PLAY, 0, e, 0));
-      call_run_ability(k, e, -1, PK_NONE, true);
-    } else {
-      wk_push(k, mk_hdr(F_UNIT_PLAY, 1, e, 0));
-      call_move(k, e);
-    }
-  }
-  MSB_HD MSB_INL void h_unit_play(Wk& k, const uint32_t hdr) {
-    const int top = k.sp - 1, e = hdr_a(hdr);
-    if (hdr_st(hdr) == 0) {
-      m.sk_st(top, mk_hdr(F_UNIT_PLAY, 1, e, 0));
-      call_move(k, e);
-      return;
-    }
+    move(e);
     e_set_flag(e, EF_RESOLVING_PLAY, false);
-    k.sp = top;
   }
   // Structure.play, structure.py:45-50
-  MSB_HD MSB_INL void call_structure_play(Wk& k, int e, P position) {
+  MSB_HD MSB_INL void structure_play(int e, P position) {
     board_set(position, e);
-    if (e_card_trigger(e) == TR_ON_PLAY) call_run_ability(k, e, -1, PK_NONE, true);
+    if (e_card_trigger(e) == TR_ON_PLAY) run_ability(e, -1, PK_NONE, true);
   }
   MSB_HD MSB_INL bool e_resolving_play(int e) const { return (e_flags(e) & EF_RESOLVING_PLAY) != 0; }
   // Unit.gain_speed, unit.py:277-280
@@ -1844,18 +1640,20 @@ struct Engine {
     set_path(e, e_resolving_play(e));
     m.st8g(eg(e), EO_MOV, mv);
   }
-  // Unit.command, unit.py:282-289.  Frame F_CMD_TAIL {hdr: e, fixedly_forward as it was}: behind the move.
-  MSB_HD MSB_INL void call_command(Wk& k, int e) {
+  // Unit.command, unit.py:282-289
+  MSB_HD MSB_INL void command(int e) {
     if (!need_unit(e)) return;
     const int sv = ctx_enter(e);
-    if (fault()) return;
-    wk_push_ctx(k, sv);
-    const bool ff = e_ff(e);
+    command_impl(e);
+    ctx_leave(sv);
+  }
+  MSB_HD MSB_A_MISC void command_impl(int e) {
+    MSB_SCOPE(PS_COMMAND);
+    bool ff = e_ff(e);
     e_set_flag(e, EF_FF, true);
     set_path(e, false);
-    if (fault()) return;
-    wk_push(k, mk_hdr(F_CMD_TAIL, 0, e, ff ? 1 : 0));
-    call_move(k, e);
+    move(e);
+    e_set_flag(e, EF_FF, ff);
   }
   // Unit.convert, unit.py:291-293
   MSB_HD MSB_INL void convert(int e) {
@@ -1871,6 +1669,7 @@ struct Engine {
     ctx_leave(sv);
   }
   MSB_HD MSB_A_MISC void teleport_impl(int e, P dest) {
+    MSB_SCOPE(PS_TELEPORT);
     if (at(dest) == AT_NONE) {
       board_set(e_pos(e), -1);
       board_set(dest, e);
@@ -1887,6 +1686,7 @@ struct Engine {
     ctx_leave(sv);
   }
   MSB_HD MSB_A_MISC void push_pull_impl(int e, P from, bool is_push) {
+    MSB_SCOPE(PS_PUSH_PULL);
     P pos = e_pos(e);
     int dx = 0, dy = 0;
     if (from.y < pos.y)
@@ -1910,11 +1710,14 @@ struct Engine {
     int y = e_pos(e).y;
     if (pl_front(o) > y) set_pl_front(o, y > 1 ? y : 1);
   }
-  // Unit.force_attack, unit.py:341-371 (the move at its end is a tail call)
-  MSB_HD MSB_INL void call_force_attack(Wk& k, int e, P dest) {
+  // Unit.force_attack, unit.py:341-371
+  MSB_HD MSB_INL void force_attack(int e, P dest) {
     const int sv = ctx_enter(e);
-    if (fault()) return;
-    wk_push_ctx(k, sv);
+    force_attack_impl(e, dest);
+    ctx_leave(sv);
+  }
+  MSB_HD MSB_A_MISC void force_attack_impl(int e, P dest) {
+    MSB_SCOPE(PS_FORCE_ATTACK);
     P pos = e_pos(e);
     if ((dest.x != pos.x && dest.y != pos.y) || at(dest) == AT_NONE) return;
     bool vertical = dest.x == pos.x;
@@ -1937,11 +1740,12 @@ struct Engine {
     if (n > 0) {
       e_set_path(e, packed);
       m.st8g(eg(e), EO_PATHN, n);
-      call_move(k, e);
+      move(e);
     }
   }
   // Board.spawn_token_unit, board.py:298-311 (types always given by the cards)
   MSB_HD MSB_A_MISC int spawn_token_unit(int owner, P position, int strength, int unit_type) {
+    MSB_SCOPE(PS_SPAWN);
     int e = new_entity(TOKEN_UNIT_BASE + unit_type, owner, strength, 1, false);
     if (fault()) return e;
     board_set(position, e);
@@ -1956,6 +1760,7 @@ struct Engine {
     ctx_leave(sv);
   }
   MSB_HD MSB_A_MISC void respawn_impl(int e, P position, int strength) {
+    MSB_SCOPE(PS_RESPAWN);
     int c = e_card(e);
     int ne;
     if (c < NUM_CARDS)
@@ -2012,6 +1817,7 @@ struct Engine {
 
   // Player.draw, player.py:46-52: numpy choice(deck, size=1, p=w/sum(w))
   MSB_HD MSB_A_DRAW void draw(int o, int amount) {
+    MSB_SCOPE(PS_DRAW);
     for (int k = 0; k < amount; k++) {
       int n = pl_deck_n(o);
       if (n == 0) {
@@ -2078,7 +1884,14 @@ struct Engine {
     m.st64(H_HIST, h);
   }
   // Player.play, player.py:68-77.  has_pos=false <=> position None
-  MSB_HD MSB_INL void call_player_play(Wk& k, int o, int index, P position, bool has_pos) {
+  MSB_HD MSB_INL void player_play(int o, int index, P position, bool has_pos) {
+    MSB_PRECALL();
+    player_play_impl(o, index, position, has_pos);
+    MSB_POSTCALL(PS_PLAYER_PLAY);
+    
+  }
+  MSB_HD MSB_A_PLAY void player_play_impl(int o, int index, P position, bool has_pos) {
+    MSB_SCOPE(PS_PLAYER_PLAY);
     int card = hand_card(o, index), fl = hand_flags(o, index);
     int strength = inst_strength(card, fl, hand_x(o, index));   // target.copy() copies the instance's strength
     add_history(o, card);
@@ -2092,7 +1905,7 @@ struct Engine {
         set_fault(FAULT_PY_EXCEPTION);
         return;
       }
-      call_unit_play(k, e, position);
+      unit_play(e, position);
     } else if (ci.kind == KIND_STRUCT) {
       int e = new_entity(card, o, strength, 0, false);
       if (fault()) return;
@@ -2101,13 +1914,13 @@ struct Engine {
         set_fault(FAULT_PY_EXCEPTION);
         return;
       }
-      call_structure_play(k, e, position);
+      structure_play(e, position);
     } else {
-      call_spell_play(k, card, o, position, has_pos);
+      spell_play(card, o, position, has_pos);
     }
   }
   // Spell.play, spell.py:22-24
-  MSB_HD MSB_INL void call_spell_play(Wk& k, int card, int o, P position, bool has_pos) {
+  MSB_HD MSB_INL void spell_play(int card, int o, P position, bool has_pos) {
     const CardInfo& ci = g_cards[card];
     bool go = true;
     if (ci.tgt.has) {
@@ -2120,7 +1933,7 @@ struct Engine {
         return;
       }
     }
-    if (go) call_run_ability(k, -1, card | (o << 8), has_pos ? p_pack(position) : PK_NONE, true);
+    if (go) run_ability(-1, card | (o << 8), has_pos ? p_pack(position) : PK_NONE, true);
   }
   // Player.cycle, player.py:79-81
   MSB_HD MSB_INL void cycle(int o, int hand_index) {
@@ -2135,6 +1948,7 @@ struct Engine {
   // Board.flip, board.py:94-115.  H_TOPLAY has already been toggled by the caller, which swaps
   // local/remote; entity.player keeps the same PlayerOrder through the "ownership swap".
   MSB_HD MSB_A_TURN void flip() {
+    MSB_SCOPE(PS_FLIP);
     set_pl_front(0, 4 - pl_front(0));
     set_pl_front(1, 4 - pl_front(1));
     // 180-degree rotation: new row y = byte-reversed old row 4-y
@@ -2154,9 +1968,9 @@ struct Engine {
       }
     }
   }
-  // Board.to_next_turn, board.py:117-145.  Frame F_TURN {hdr: state, i, ns; six words: the snapshot of entity OBJECTS
-  // being iterated (fact #6), as slot ids}: state 0 = the friendly structures' TURN_START abilities, 1 = the units' moves.
-  MSB_HD MSB_INL void call_next_turn(Wk& k) {
+  // Board.to_next_turn, board.py:117-145
+  MSB_HD MSB_A_TURN void to_next_turn() {
+    MSB_SCOPE(PS_NEXT_TURN);
     m.st8(H_PHASE, PH_TURN_END);
     int ender = cp();
     fill_hand(ender);
@@ -2172,48 +1986,29 @@ struct Engine {
     int ncp = (ender == local()) ? remote() : local();
     m.st8(H_CP, ncp);
     m.st8(pl(ncp, P_FLAGS), m.ld8(pl(ncp, P_FLAGS)) | 3);
+    // snapshots of entity objects (fact #6): the slot ids, one byte each, in the words of a second list value
     PList hs;
     hs.clear();
     PList snap = get_targets(ncp, mk_tgt(TK_STRUCTURE, TS_FRIENDLY), PK_NONE);
     int ns = snap.n();
     for (int i = 0; i < ns; i++) hs.set8(i, at(snap.at(i)));
-    wk_push_list(k, hs);
-    wk_push(k, mk_hdr(F_TURN, 0, 0, ns));
-  }
-  MSB_HD MSB_INL void h_turn(Wk& k, const uint32_t hdr) {
-    const int top = k.sp - 1;
-    int i = hdr_a(hdr), ns = hdr_b(hdr);
-    PList hs = wk_list(top - 1, 0);
-    if (hdr_st(hdr) == 0) {
-      while (i < ns) {
-        const int s = hs.get8(i);
-        i++;
-        // structure.is_at_turn_start: token structures and b001 run the empty base ability
-        if (e_card_trigger(s) == TR_TURN_START) {
-          m.sk_st(top, mk_hdr(F_TURN, 0, i, ns));
-          call_run_ability(k, s, -1, m.ld8g(eg(s), EO_POS) /*unused*/, true);
-          return;
-        }
-      }
-      // the units as they stand once every structure has acted
-      PList snap = get_targets(cp(), mk_tgt(TK_UNIT, TS_FRIENDLY), PK_NONE);
-      ns = snap.n();
-      for (int j = 0; j < ns; j++) hs.set8(j, at(snap.at(j)));
-      wk_store_list(top - 1, hs);
-      i = 0;
-    }
-    if (i < ns) {
-      const int u = hs.get8(i);
-      m.sk_st(top, mk_hdr(F_TURN, 1, i + 1, ns));
-      set_path(u, false);
+    for (int i = 0; i < ns; i++) {
+      int s = hs.get8(i);
+      // structure.is_at_turn_start: token structures and b001 run the empty base ability
+      if (e_card_trigger(s) == TR_TURN_START) run_ability(s, -1, m.ld8g(eg(s), EO_POS) /*unused*/, true);
       if (fault()) return;
-      call_move(k, u);
-      return;
+    }
+    snap = get_targets(ncp, mk_tgt(TK_UNIT, TS_FRIENDLY), PK_NONE);
+    ns = snap.n();
+    for (int i = 0; i < ns; i++) hs.set8(i, at(snap.at(i)));
+    for (int i = 0; i < ns; i++) {
+      int u = hs.get8(i);
+      set_path(u, false);
+      move(u);
+      if (fault()) return;
     }
     m.st8(H_PHASE, PH_PLAY);
-    k.sp = top - 6;
   }
-
 
   // Stormbound.have_winner, games/stormbound.py:560-561 (strict: a base at exactly 0 is alive)
   MSB_HD MSB_INL bool have_winner() const { return pl_base(0) < 0 || pl_base(1) < 0; }
@@ -2221,6 +2016,7 @@ struct Engine {
   // Stormbound.legal_actions + Action.to_int, games/stormbound.py:528-557, 258-290 -> 156-bit mask
   // (three 64-bit words in a register vector)
   MSB_HD MSB_A_LEGAL msb_u64x4 legal_mask_v() {
+    MSB_SCOPE(PS_LEGAL);
     unsigned long long m0 = 0, m1 = 0, m2 = 0;
     int lo = local();
     int hn = pl_hand_n(lo), mana = pl_mana(lo), fl = pl_front(lo);
@@ -2282,13 +2078,18 @@ struct Engine {
 
   // Stormbound.step, games/stormbound.py:318-373 (without the observation; see observe.inc).
   // The caller guarantees `action` is in legal_actions().  Returns reward | done << 1 as the reference
-  // computes them.  Frame F_STEP {hdr: state, action}: state 0 = the card has been played, 1 = the turn has been passed on.
+  // computes them (in registers: no out-pointers behind a non-inlined call).
   MSB_HD MSB_INL int step(int action) {
-    Wk k{0, 0};
+    MSB_PRECALL();
+    int r_ = step_impl(action);
+    MSB_POSTCALL(PS_STEP);
+    return r_;
+  }
+  MSB_HD MSB_A_STEP int step_impl(int action) {
+    MSB_SCOPE(PS_STEP);
+    int result = 0;
     begin_step();
-    if (fault()) return 0;
     int lo = local();
-    wk_push(k, mk_hdr(F_STEP, 0, action, 0));
     if (action < 148) {
       // PLACE: card = a//16, tile = a%16 over y=4..1,x=0..3.  USE: card = (a-64)//21, idx = (a-64)%21; the
       // countdown executes at the idx-th tile of y=4..0,x=0..3 -- one tile after the one Action.to_int
@@ -2300,7 +2101,7 @@ struct Engine {
         P pos{idx & 3, 4 - (idx >> 2)};
         bool has_pos = place || g_cards[hand_card(lo, ci)].tgt.has != 0;
         set_pl_mana(lo, pl_mana(lo) - hand_cost(lo, ci));
-        call_player_play(k, lo, ci, pos, has_pos);
+        player_play(lo, ci, pos, has_pos);
       }
     } else if (action < 152) {
       cycle(lo, action - 148);
@@ -2318,85 +2119,17 @@ struct Engine {
 #endif
       m.st8(pl(lo, P_FLAGS), m.ld8(pl(lo, P_FLAGS)) & ~2);
     }
-    run(k);
-    return k.result;   // 0 if the play raised; what was computed before the turn was passed on otherwise
-  }
-  MSB_HD MSB_INL void h_step(Wk& k, const uint32_t hdr) {
-    const int top = k.sp - 1, action = hdr_a(hdr);
-    if (hdr_st(hdr) == 0) {
-      // done = have_winner() or len(legal_actions()) == 0; legal_actions() is never empty (PASS)
-      k.result = (pl_base(remote()) <= 0 ? 1 : 0) | (have_winner() ? 2 : 0);
-      if (action == 155) {
-        m.st8(H_TOPLAY, local() ^ 1);
-        flip();
-        m.sk_st(top, mk_hdr(F_STEP, 1, action, 0));
-        call_next_turn(k);
-        return;
-      }
+    if (fault()) return 0;
+    // done = have_winner() or len(legal_actions()) == 0; legal_actions() is never empty (PASS)
+    result = (pl_base(remote()) <= 0 ? 1 : 0) | (have_winner() ? 2 : 0);
+    if (action == 155) {
+      m.st8(H_TOPLAY, lo ^ 1);
+      flip();
+      to_next_turn();
     }
     if (m.ld8(H_RNGOVER)) set_fault(FAULT_RNG_OVERRUN);
-    k.sp = top;
+    return result;
   }
-
-  // The handlers of the remaining frames, and run(): the only loop of a step.
-  MSB_HD MSB_INL void h_ctx_leave(Wk& k, const uint32_t hdr) {
-    ctx_leave(hdr_a(hdr));
-    k.sp--;
-  }
-  MSB_HD MSB_INL void h_destroy_tail(Wk& k, const uint32_t) {
-    recalc_front_after_destroy();
-    k.sp--;
-  }
-  MSB_HD MSB_INL void h_cmd_tail(Wk& k, const uint32_t hdr) {
-    e_set_flag(hdr_a(hdr), EF_FF, hdr_b(hdr) != 0);
-    k.sp--;
-  }
-  MSB_HD MSB_INL void wk_dispatch(Wk& k, int fn, const uint32_t hdr) {
-    switch (fn) {
-      case F_STEP: h_step(k, hdr); break;
-      case F_UNIT_PLAY: h_unit_play(k, hdr); break;
-      case F_MOVE: h_move(k, hdr); break;
-      case F_RUNAB: h_runab(k, hdr); break;
-      case F_CTXLEAVE: h_ctx_leave(k, hdr); break;
-      case F_DESTROY_TAIL: h_destroy_tail(k, hdr); break;
-      case F_CMD_TAIL: h_cmd_tail(k, hdr); break;
-      case F_EACH: h_each(k, hdr); break;
-      case F_AFTER: h_after(k, hdr); break;
-      case F_TURN: h_turn(k, hdr); break;
-      default: set_fault(FAULT_UNSUPPORTED); break;   // not a frame: cannot happen
-    }
-  }
-  // Run the work stack until it is empty.  On the device the lanes of a wave are grouped by the function of their top
-  // frame first (a "waterfall": take the first waiting lane's function as a wave-uniform value, serve the lanes
-  // holding it, repeat), so the switch runs on a scalar and lanes that are in the same function -- whatever path of
-  // calls took them there -- execute it together.
-  MSB_HD MSB_INL void run(Wk& k) {
-    while (k.sp > 0 && !fault()) {
-      const uint32_t hdr = m.sk_ld(k.sp - 1);
-      const int fn = hdr_fn(hdr);
-#if defined(__HIP_DEVICE_COMPILE__)
-      int fv = fn;
-      asm volatile("" : "+v"(fv));   // an opaque copy: under `fn == f0` the compiler would switch on the vector `fn` again
-      for (unsigned long long todo = __ballot(1); todo;) {
-        const int leader = __builtin_ctzll(todo);
-        const int f0 = __builtin_amdgcn_readlane(fn, leader), f1 = __builtin_amdgcn_readlane(fv, leader);
-        const bool mine = fn == f0;
-        todo &= ~__ballot(mine);
-        if (mine) {
-          // opaque copies: whatever a handler derives from the header or the stack pointer is computed inside the
-          // branch that runs it (hoisted out of this loop, the sub-expressions of ALL handlers would be computed for
-          // every frame -- and spilled)
-          uint32_t hv = hdr;
-          asm volatile("" : "+v"(hv), "+v"(k.sp));
-          wk_dispatch(k, f1, hv);
-        }
-      }
-#else
-      wk_dispatch(k, fn, hdr);
-#endif
-    }
-  }
-
 
   // Stormbound.expert_action, games/stormbound.py:563-637: the reference's scripted opponent.  Draws from
   // the GAME's stream (self.random).  May return PASS while plays are still legal -- that is how it ends a turn.

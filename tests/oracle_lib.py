@@ -13,6 +13,9 @@ ORACLE_DIR = os.path.join(REPO, "oracle")
 LIB_PATH = os.path.join(ORACLE_DIR, "liboracle.so")
 LIB_PATH_EXT = os.path.join(ORACLE_DIR, "liboracle_ext.so")   # extended record (ua20, b005)
 LIB_PATH_BIG = os.path.join(ORACLE_DIR, "liboracle_big.so")   # large extended record (extended=2)
+# host builds of the PRODUCT's rules core (explicit work stack; oracle/oracle.cpp -DORC_PRODUCT_CORE): the same C entry
+# points over the other implementation of the rules, for the CPU-side checks of the product core
+PRODUCT_HOST = tuple(os.path.join(ORACLE_DIR, n) for n in ("libproduct_host.so", "libproduct_host_ext.so", "libproduct_host_big.so"))
 
 
 def build():
@@ -22,9 +25,11 @@ def build():
 _libs = {}
 
 
-def lib(extended=False):
-    if extended not in _libs:
-        path = extended if isinstance(extended, str) else (LIB_PATH, LIB_PATH_EXT, LIB_PATH_BIG)[int(extended)]
+def lib(extended=False, core="oracle"):
+    key = (extended, core)
+    if key not in _libs:
+        paths = PRODUCT_HOST if core == "product" else (LIB_PATH, LIB_PATH_EXT, LIB_PATH_BIG)
+        path = extended if isinstance(extended, str) else paths[int(extended)]
         if not os.path.exists(path):
             build()
         L = ctypes.CDLL(path)
@@ -60,8 +65,8 @@ def lib(extended=False):
         L.orc_rng_random.argtypes = [ctypes.c_uint32, ctypes.c_int, ctypes.c_void_p]
         L.orc_rng_randint.argtypes = [ctypes.c_uint32, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
         L.orc_rng_shuffle.argtypes = [ctypes.c_uint32, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
-        _libs[extended] = L
-    return _libs[extended]
+        _libs[key] = L
+    return _libs[key]
 
 
 def _p(a):
@@ -78,8 +83,10 @@ def fnv1a64(data):
 class Oracle:
     """n independent games replayed on the CPU."""
 
-    def __init__(self, n=1, extended=False):
-        self.L = lib(extended)
+    def __init__(self, n=1, extended=False, core=None):
+        # core: "oracle" (the recursive restatement, the checker) or "product" (host build of the product's rules core);
+        # MSB_ORACLE_CORE=product switches the default, which runs the whole golden suite over the product core
+        self.L = lib(extended, core or os.environ.get("MSB_ORACLE_CORE", "oracle"))
         self.h = ctypes.c_void_p(self.L.orc_create(n))
         self.n = n
 
