@@ -70,14 +70,16 @@ struct DevBuffers {
   uint32_t* wk_ovf;    // overflow blocks of the rules core's work stack: [workgroup][SK_CAP - SKW][lanes stepping games in it]
 };
 
-// Work-stack words per game kept in LDS (state.h LaneMem): the frames of a step with a handful of nested abilities.
-// Deeper stacks continue in the workgroup's overflow block in HBM.
+// Work-stack words per game kept in LDS (state.h LaneMem, rules.h wk_reserve): 98 % of the steps of a neutral-deck game
+// never hold more than 8; a step that wants more than SKW - SK_NEED when it enters an ability or a move parks what it has
+// in the workgroup's eviction block in HBM.
 #if defined(MSB_SKW)
 constexpr int SKW = MSB_SKW;
 #else
-constexpr int SKW = 32;
+constexpr int SKW = 24;
 #endif
-constexpr int OVF_WORDS = SK_CAP - SKW;   // per stepping lane
+static_assert(SKW >= SK_NEED + 9 && SKW * 4 >= 80, "room for the largest frame + the eviction mark + what a handler pushes; the candidates' features overlay their stacks");
+constexpr int OVF_WORDS = SK_CAP;   // per stepping lane
 
 enum { ST_LOOKAHEAD = 0, ST_DECISIONS = 1, ST_FINISHED = 2, ST_FAULTS = 3, ST_CAPFAULTS = 4, ST_LACAPFAULTS = 5, ST_N = 6, ST_PROF = 8, ST_WORDS = 32, PROF_WORDS = 138 };
 // Phase timing of k_decide (profiling build only, -DMSB_PROF=1 -> libmonsoon_hip_prof.so; never the product):
@@ -196,7 +198,7 @@ constexpr int LDS_ORIGIN = LDS_RECORDS;
 // score + argmax + commit each) before it writes the record back and takes the next game.
 // Dynamic LDS map (bytes): weight table | [PRIV, +SG*U*16) candidate records, lane-interleaved in 16-byte granules |
 // the game's current record | the parked best successor | 10 weights + 10 "before" + 10 "best after" features |
-// the candidates' work stacks (SKW words each, interleaved word by word)
+// the candidates' "after" features | the candidates' work stacks (SKW words each, interleaved word by word)
 // ------------------------------------------------------------------------------------------------
 __device__ MSB_INL int nth_set_bit(const uint64_t mask[3], int k) {
   for (int w = 0; w < 3; w++) {
@@ -218,7 +220,8 @@ struct DecideLds {
   static constexpr int PAR = PRIV + PRIV_BYTES;      // the game's current record
   static constexpr int BEST = PAR + SG * 16;         // best successor so far of a decision that needs several passes
   static constexpr int WF = BEST + SG * 16;          // 10 weights + 10 "before" features + 10 features of the best successor (f64)
-  static constexpr int SKB = WF + 240;               // work stacks of the U candidate lanes
+  static constexpr int SKB = WF + 240;               // work stacks of the U candidate lanes ...
+  static constexpr int CF = SKB;                     // ... and, once a pass has stepped (stacks empty), their ten "after" features each (f64)
   static constexpr int TOTAL = SKB + U * SKW * 4;
 };
 
@@ -248,6 +251,7 @@ __device__ MSB_INL void play_game(const DevBuffers& b, const int g, const int la
   MSB_AS_LDS u32x4* priv = (MSB_AS_LDS u32x4*)(uintptr_t)L::PRIV;
   MSB_AS_LDS u32x4* bestcol = (MSB_AS_LDS u32x4*)(uintptr_t)L::BEST;
   MSB_AS_LDS double* wf = (MSB_AS_LDS double*)(uintptr_t)L::WF;
+  MSB_AS_LDS double* cf = (MSB_AS_LDS double*)(uintptr_t)(L::CF + (lane < U ? lane : 0) * 80);   // this candidate lane's features
   u32x4* grec = (u32x4*)(b.state + (size_t)g * SW);
   for (int c = lane; c < SG; c += 64) par[c] = grec[c];   // one coalesced 16-B-per-lane pass
   __syncthreads();
@@ -289,10 +293,7 @@ __device__ MSB_INL void play_game(const DevBuffers& b, const int g, const int la
       // The "before" features of this decision are the "after" features the previous decision computed for the
       // successor it committed (same state, same mover); only the first decision of a call computes them.
       if (!before_raises && !have_before) {
-        double fb[10];
-        pe.features(fb);
-        if (lane == 0)
-          for (int i = 0; i < 10; i++) wf[10 + i] = fb[i];
+        if (lane == 0) pe.features(wf + 10);
       }
     }
     __syncthreads();
@@ -318,7 +319,6 @@ __device__ MSB_INL void play_game(const DevBuffers& b, const int g, const int la
       int my_feat = 0;
       int f = 0;
       bool raises = false;
-      double fa[10];
       // copy.deepcopy (stream window included) for the whole pass, by all 64 lanes: granule idx of the interleaved
       // candidate image is record granule idx / U for column idx % U
       {
@@ -344,8 +344,8 @@ __device__ MSB_INL void play_game(const DevBuffers& b, const int g, const int la
       PROF_MARK(4);   // step
       if (active) {
         if (f == 0 && !before_raises && !raises) {
-          ce.features(fa);
-          s = CandEngine::action_score_lds(wf, fa);
+          ce.features(cf);
+          s = CandEngine::action_score_lds(wf, cf);
           my_feat = 1;
         }
         if (write_scores) b.scores[(size_t)g * MONSOON_NUM_ACTIONS + a] = s;
@@ -381,7 +381,7 @@ __device__ MSB_INL void play_game(const DevBuffers& b, const int g, const int la
         cfault = __builtin_amdgcn_readlane(my_fault, wl);
         feat_ok = __builtin_amdgcn_readlane(my_feat, wl);
         if (lane == wl && my_feat)   // the winner keeps its features: the next decision's "before" side
-          for (int i = 0; i < 10; i++) wf[20 + i] = fa[i];
+          for (int i = 0; i < 10; i++) wf[20 + i] = cf[i];
         if (multi) {
           __syncthreads();
           for (int c = lane; c < SG; c += 64) bestcol[c] = priv[c * U + wl];

@@ -26,6 +26,10 @@ static inline void msb_fault_trace(int code) {
 }
 #endif
 
+#if defined(MSB_COUNT_FRAMES) && !defined(__HIPCC__)
+static long long msb_frame_count[32];   // study build of the host library: handler invocations per frame type, [0] = all, [15] = deepest stack, [16..27] = histogram of sp / 4
+#endif
+
 namespace msb {
 
 struct P {
@@ -1321,10 +1325,38 @@ struct Engine {
   //   call_X(k, ...): the part of X before its first nested call runs at once, in the caller; what is left of X, if
   //   anything, waits in a frame.  The caller tells "completed" from "pending" by the stack pointer.
   struct Wk {
-    int sp;       // words in use on this game's work stack
+    int sp;       // words in use on this game's work stack (the resident part)
     int result;   // Stormbound.step's reward | done << 1
+    int base;     // words evicted so far (wk_evict; always 0 on the host)
+    int seg;      // evictions pending
   };
-  enum : int { F_STEP = 1, F_UNIT_PLAY, F_MOVE, F_RUNAB, F_CTXLEAVE, F_DESTROY_TAIL, F_CMD_TAIL, F_EACH, F_AFTER, F_TURN };
+  enum : int { F_MOVE = 1, F_RUNAB, F_CTXLEAVE, F_DESTROY_TAIL, F_CMD_TAIL, F_EACH, F_AFTER, F_TURN, F_EVICTED };
+  // Words of a frame, by function (the eviction below moves whole frames).
+  MSB_HD MSB_INL static int frame_words(int fn) {
+    return fn == F_MOVE ? 4 : fn == F_RUNAB ? 2 : fn == F_EACH ? 8 : fn == F_AFTER ? 2 : fn == F_TURN ? 7 : 1;
+  }
+  // Where the resident part of the stack (M::SKW words of LDS on the device) could run short during the next handler --
+  // one handler pushes at most SK_NEED words before it returns to run() -- everything below the top frame moves out to
+  // the eviction block, the top frame slides down and an F_EVICTED frame {hdr: n} marks the place: when that frame is
+  // on top again, the n words come back.  Handlers never notice.
+  MSB_HD MSB_INL void wk_evict(Wk& k, int fn) {
+    const int fs = frame_words(fn), n = k.sp - fs;
+    for (int i = 0; i < n; i++) M::ovf_st(k.base + i, m.sk_ld(i));
+    for (int j = 0; j < fs; j++) m.sk_st(1 + j, m.sk_ld(n + j));
+    m.sk_st(0, mk_hdr(F_EVICTED, 0, n, 0));
+    k.base += n;
+    k.seg++;
+    k.sp = 1 + fs;
+  }
+  MSB_HD MSB_INL void h_evicted(Wk& k, const uint32_t hdr) {
+    const int n = hdr_a(hdr);
+    k.base -= n;
+    k.seg--;
+    for (int i = 0; i < n; i++) m.sk_st(i, M::ovf_ld(k.base + i));
+    k.sp = n;
+  }
+  // Called where a step enters an ability or a move: false = the stack is deeper than any chain the depth limit allows.
+  MSB_HD MSB_INL bool wk_reserve(const Wk& k) const { return k.base + k.sp - k.seg <= SK_CAP - SK_MARGIN; }
   MSB_HD MSB_INL static uint32_t mk_hdr(int fn, int st, int a, int b) {
     return (uint32_t)(fn & 0xff) | ((uint32_t)(st & 0xff) << 8) | ((uint32_t)(a & 0xff) << 16) | ((uint32_t)(b & 0xff) << 24);
   }
@@ -1403,7 +1435,7 @@ struct Engine {
     if (fault()) return;
     wk_push_ctx(k, sv);
     const int d = m.ld8(H_DEPTH);
-    if (d >= MAX_DEPTH || k.sp > SK_CAP - SK_MARGIN) {
+    if (d >= MAX_DEPTH || !wk_reserve(k)) {
       set_fault(FAULT_DEPTH);
       return;
     }
@@ -1634,30 +1666,61 @@ struct Engine {
     m.st8g(eg(e), EO_PATHN, n);
   }
 
-  // Unit.move, unit.py:124-203.  Frame F_MOVE {hdr: state, e, recursion depth outside; w1: the path list bound when
-  // the loop started (fact #5); w2: i | n << 3 | move_id << 8 | target << 16 | flags << 24 (1 is_attacked,
+  // Unit.move, unit.py:124-203.  Frame F_MOVE {hdr: state, e, recursion depth outside | MV_PLAYED; w1: the path list
+  // bound when the loop started (fact #5); w2: i | n << 3 | move_id << 8 | target << 16 | flags << 24 (1 is_attacked,
   // 2 target_pending, 4 local_pending); w3: the target's strength before the fight}.  The states are the places where
-  // the reference's move() is waiting for a nested call.
+  // the reference's move() is waiting for a nested call; MV_START is the call itself (a move pushed below the ability
+  // that runs first: Unit.play).  MV_PLAYED: this is the move at the end of Unit.play (unit.py:74-76), which clears
+  // resolving_play behind it.
   enum : int { MV_ENTRY = 0, MV_POISONED, MV_BEFORE_MOVING, MV_STEP, MV_BASE_HIT, MV_FIGHT, MV_STRUCK, MV_STRUCK_BACK,
-               MV_TARGET_DEAD, MV_SELF_DEAD, MV_AFTER_ATTACK, MV_DONE };
-  MSB_HD MSB_INL void call_move(Wk& k, int e) {
+               MV_TARGET_DEAD, MV_SELF_DEAD, MV_AFTER_ATTACK, MV_DONE, MV_START };
+  static constexpr int MV_PLAYED = 0x80;
+  // the entry of move(): the world of the unit, the recursion guard.  Returns the depth outside, -1 if the step has faulted.
+  MSB_HD MSB_INL int move_enter(Wk& k, int e) {
     const int sv = ctx_enter(e);
-    if (fault()) return;
+    if (fault()) return -1;
     wk_push_ctx(k, sv);
     const int d = m.ld8(H_DEPTH);
-    if (d >= MAX_DEPTH || k.sp > SK_CAP - SK_MARGIN) {
+    if (d >= MAX_DEPTH || !wk_reserve(k)) {
       set_fault(FAULT_DEPTH);
-      return;
+      return -1;
     }
     m.st8(H_DEPTH, d + 1);
-    wk_push(k, 0);
-    wk_push(k, 0);
-    wk_push(k, 0);
-    wk_push(k, mk_hdr(F_MOVE, MV_ENTRY, e, d));
+    return d;
   }
-  MSB_HD MSB_INL void h_move(Wk& k, const uint32_t hdr) {
+  MSB_HD MSB_INL void call_move(Wk& k, int e, int played = 0) {
+    const int d = move_enter(k, e);
+    if (d < 0) return;
+    wk_push(k, 0);
+    wk_push(k, 0);
+    wk_push(k, 0);
+    wk_push(k, mk_hdr(F_MOVE, MV_ENTRY, e, d | played));
+  }
+  // a move that starts when the frames pushed after it have run
+  MSB_HD MSB_INL void call_move_later(Wk& k, int e, int played) {
+    wk_push(k, 0);
+    wk_push(k, 0);
+    wk_push(k, 0);
+    wk_push(k, mk_hdr(F_MOVE, MV_START, e, played));
+  }
+  MSB_HD MSB_INL void h_move(Wk& k, uint32_t hdr) {
+    if (hdr_st(hdr) == MV_START) {
+      // the frame holds nothing yet: take it off, enter (which may leave a world mark where it was), put it back
+      const int e0 = hdr_a(hdr), played = hdr_b(hdr) & MV_PLAYED;
+      k.sp -= 4;
+      const int d0 = move_enter(k, e0);
+      if (d0 < 0) return;
+      k.sp += 4;
+      hdr = mk_hdr(F_MOVE, MV_ENTRY, e0, d0 | played);
+      if (REM_LISTS) {   // the frame may have moved up by the world mark
+        m.sk_st(k.sp - 2, 0);
+        m.sk_st(k.sp - 3, 0);
+        m.sk_st(k.sp - 4, 0);
+      }
+    }
     const int top = k.sp - 1;
-    const int e = hdr_a(hdr), d = hdr_b(hdr);
+    const int e = hdr_a(hdr), d = hdr_b(hdr) & 0x7f;
+    const int played_tail = hdr_b(hdr) & MV_PLAYED;
     uint32_t path = m.sk_ld(top - 1);
     const uint32_t w2 = m.sk_ld(top - 2);
     int i = (int)(w2 & 7), n = (int)((w2 >> 3) & 7), current_id = (int)((w2 >> 8) & 0xff), target = (int)((w2 >> 16) & 0xff);
@@ -1795,6 +1858,7 @@ struct Engine {
     }
   done:
     m.st8(H_DEPTH, d);
+    if (played_tail) e_set_flag(e, EF_RESOLVING_PLAY, false);   // Unit.play's last line
     k.sp = top - 3;
     return;
   wait:
@@ -1802,34 +1866,23 @@ struct Engine {
     m.sk_st(top - 2, (uint32_t)(i & 7) | ((uint32_t)(n & 7) << 3) | ((uint32_t)(current_id & 0xff) << 8) | ((uint32_t)(target & 0xff) << 16) |
                          ((uint32_t)(flags & 0xff) << 24));
     m.sk_st(top - 3, (uint32_t)(cached & 0xffff));
-    m.sk_st(top, mk_hdr(F_MOVE, next, e, d));
+    m.sk_st(top, mk_hdr(F_MOVE, next, e, d | played_tail));
 #undef MV_WAIT
 #undef MV_CALLED
   }
 
-  // Unit.play, unit.py:66-76.  Frame F_UNIT_PLAY {hdr: state, e}: state 0 = the ON_PLAY ability has returned, 1 = move() has.
+  // Unit.play, unit.py:66-76: the ON_PLAY ability, then the move, whose frame also carries play()'s last line (MV_PLAYED)
   MSB_HD MSB_INL void call_unit_play(Wk& k, int e, P position) {
     e_set_flag(e, EF_RESOLVING_PLAY, true);
     board_set(position, e);
     set_path(e, true);
     if (fault()) return;
     if (e_card_trigger(e) == TR_ON_PLAY) {
-      wk_push(k, mk_hdr(F_UNIT_PLAY, 0, e, 0));
+      call_move_later(k, e, MV_PLAYED);   // below the ability: starts when the ability has returned
       call_run_ability(k, e, -1, PK_NONE, true);
     } else {
-      wk_push(k, mk_hdr(F_UNIT_PLAY, 1, e, 0));
-      call_move(k, e);
+      call_move(k, e, MV_PLAYED);
     }
-  }
-  MSB_HD MSB_INL void h_unit_play(Wk& k, const uint32_t hdr) {
-    const int top = k.sp - 1, e = hdr_a(hdr);
-    if (hdr_st(hdr) == 0) {
-      m.sk_st(top, mk_hdr(F_UNIT_PLAY, 1, e, 0));
-      call_move(k, e);
-      return;
-    }
-    e_set_flag(e, EF_RESOLVING_PLAY, false);
-    k.sp = top;
   }
   // Structure.play, structure.py:45-50
   MSB_HD MSB_INL void call_structure_play(Wk& k, int e, P position) {
@@ -2282,13 +2335,12 @@ struct Engine {
 
   // Stormbound.step, games/stormbound.py:318-373 (without the observation; see observe.inc).
   // The caller guarantees `action` is in legal_actions().  Returns reward | done << 1 as the reference
-  // computes them.  Frame F_STEP {hdr: state, action}: state 0 = the card has been played, 1 = the turn has been passed on.
+  // computes them.  A play leaves frames for run(); so does passing the turn on, which has nothing before it.
   MSB_HD MSB_INL int step(int action) {
-    Wk k{0, 0};
+    Wk k{0, 0, 0, 0};
     begin_step();
     if (fault()) return 0;
     int lo = local();
-    wk_push(k, mk_hdr(F_STEP, 0, action, 0));
     if (action < 148) {
       // PLACE: card = a//16, tile = a%16 over y=4..1,x=0..3.  USE: card = (a-64)//21, idx = (a-64)%21; the
       // countdown executes at the idx-th tile of y=4..0,x=0..3 -- one tile after the one Action.to_int
@@ -2317,25 +2369,18 @@ struct Engine {
       m.st32(pl(lo, P_HAND), a);
 #endif
       m.st8(pl(lo, P_FLAGS), m.ld8(pl(lo, P_FLAGS)) & ~2);
-    }
-    run(k);
-    return k.result;   // 0 if the play raised; what was computed before the turn was passed on otherwise
-  }
-  MSB_HD MSB_INL void h_step(Wk& k, const uint32_t hdr) {
-    const int top = k.sp - 1, action = hdr_a(hdr);
-    if (hdr_st(hdr) == 0) {
+    } else if (action == 155) {
       // done = have_winner() or len(legal_actions()) == 0; legal_actions() is never empty (PASS)
       k.result = (pl_base(remote()) <= 0 ? 1 : 0) | (have_winner() ? 2 : 0);
-      if (action == 155) {
-        m.st8(H_TOPLAY, local() ^ 1);
-        flip();
-        m.sk_st(top, mk_hdr(F_STEP, 1, action, 0));
-        call_next_turn(k);
-        return;
-      }
+      m.st8(H_TOPLAY, lo ^ 1);
+      flip();
+      call_next_turn(k);
     }
+    run(k);
+    if (fault()) return action == 155 ? k.result : 0;   // 0 if the play raised; what was computed before the turn was passed on otherwise
+    if (action != 155) k.result = (pl_base(remote()) <= 0 ? 1 : 0) | (have_winner() ? 2 : 0);
     if (m.ld8(H_RNGOVER)) set_fault(FAULT_RNG_OVERRUN);
-    k.sp = top;
+    return k.result;
   }
 
   // The handlers of the remaining frames, and run(): the only loop of a step.
@@ -2353,8 +2398,6 @@ struct Engine {
   }
   MSB_HD MSB_INL void wk_dispatch(Wk& k, int fn, const uint32_t hdr) {
     switch (fn) {
-      case F_STEP: h_step(k, hdr); break;
-      case F_UNIT_PLAY: h_unit_play(k, hdr); break;
       case F_MOVE: h_move(k, hdr); break;
       case F_RUNAB: h_runab(k, hdr); break;
       case F_CTXLEAVE: h_ctx_leave(k, hdr); break;
@@ -2363,6 +2406,7 @@ struct Engine {
       case F_EACH: h_each(k, hdr); break;
       case F_AFTER: h_after(k, hdr); break;
       case F_TURN: h_turn(k, hdr); break;
+      case F_EVICTED: h_evicted(k, hdr); break;
       default: set_fault(FAULT_UNSUPPORTED); break;   // not a frame: cannot happen
     }
   }
@@ -2372,8 +2416,9 @@ struct Engine {
   // calls took them there -- execute it together.
   MSB_HD MSB_INL void run(Wk& k) {
     while (k.sp > 0 && !fault()) {
-      const uint32_t hdr = m.sk_ld(k.sp - 1);
+      uint32_t hdr = m.sk_ld(k.sp - 1);
       const int fn = hdr_fn(hdr);
+      if (M::SKW < SK_CAP && k.sp + SK_NEED > M::SKW && fn != F_EVICTED) wk_evict(k, fn);
 #if defined(__HIP_DEVICE_COMPILE__)
       int fv = fn;
       asm volatile("" : "+v"(fv));   // an opaque copy: under `fn == f0` the compiler would switch on the vector `fn` again
@@ -2392,6 +2437,12 @@ struct Engine {
         }
       }
 #else
+#if defined(MSB_COUNT_FRAMES)
+      msb_frame_count[fn]++;
+      msb_frame_count[0]++;
+      if (k.base + k.sp > msb_frame_count[15]) msb_frame_count[15] = k.base + k.sp;
+      msb_frame_count[16 + (k.sp < 47 ? k.sp / 4 : 11)]++;
+#endif
       wk_dispatch(k, fn, hdr);
 #endif
     }

@@ -159,12 +159,15 @@ constexpr int WT_LDS = 16;       // LDS address 0 is avoided (the null LDS point
 #endif
 constexpr int WK_OVF_LDS = WT_LDS + 8 * WT_LDS_N;    // u64: global address of this workgroup's work-stack overflow block
 constexpr int LDS_RECORDS = WK_OVF_LDS + 16;         // first LDS byte the kernels may use for records
-// The work stack of the rules core (rules.h "Control flow"): SK_CAP 32-bit words per game.  On the device the first SKW
-// words of a lane's stack live in LDS (lane-interleaved like the record), deeper frames -- a chain of more than about a
-// dozen nested abilities -- spill to a per-workgroup block in HBM.  A step needs SK_MARGIN free words whenever it enters
-// an ability or a move (the two places that also count the reference's recursion depth), else it ends with FAULT_DEPTH.
-constexpr int SK_CAP = 512;
-constexpr int SK_MARGIN = 48;
+// The work stack of the rules core (rules.h "Control flow"): up to SK_CAP 32-bit words per game.  On the device a lane's
+// stack lives in SKW words of LDS (lane-interleaved like the record); whenever fewer than SK_NEED of them are free before
+// a handler runs, everything below the top frame is EVICTED to the workgroup's block in HBM and comes back when the
+// frames above it have run (rules.h wk_evict): a chain of more than a few nested abilities -- 2 % of the steps of a
+// neutral-deck game.  A stack deeper than SK_CAP - SK_MARGIN words in all ends the step with FAULT_DEPTH (40 nested
+// abilities / moves, where the reference's own recursion limit is restated, need about 530).
+constexpr int SK_CAP = 640;
+constexpr int SK_MARGIN = 32;
+constexpr int SK_NEED = 12;   // the most one handler pushes before it returns to run() (an ability: F_AFTER 2 + the damage -> destroy -> next ability chain 6; F_EACH 8; F_TURN 7)
 // card-instance flags (hand/deck entries {card, cost, flags, x}).  b305 puts the on-board structure OBJECT
 // back into the hand (cards/b305.py:40-45): such an entry aliases entity slot x while that entity is
 // on the board (CF_ALIAS) and keeps its last strength in x afterwards (CF_STR).  Both kinds have a
@@ -214,7 +217,8 @@ typedef uint32_t msb_u32x4 __attribute__((vector_size(16)));
 #if !defined(__HIPCC__)
 static thread_local int32_t* msb_trace_log = nullptr;   // {card, position} pairs (FlatMem::trace_ability)
 static thread_local int msb_trace_n = 0, msb_trace_cap = 0;
-static thread_local uint32_t msb_host_wk[512];   // SK_CAP words: the work stack of the game this thread is stepping
+static thread_local uint32_t msb_host_wk[640];   // SK_CAP words: the work stack of the game this thread is stepping
+static thread_local uint32_t msb_host_ovf[640];  // its eviction block (only the MSB_HOST_SKW build ever evicts)
 #endif
 // Host / flat: the record is a contiguous byte array.
 struct FlatMem {
@@ -248,13 +252,28 @@ struct FlatMem {
   MSB_HD MSB_INL double ldfg(int g, int k) const { return ldf(g * 16 + k); }
   MSB_HD MSB_INL void stfg(int g, int k, double v) { stf(g * 16 + k, v); }
   MSB_HD MSB_INL static double wtab(int age) { return g_wtab.v[age & AGE_MAX]; }
-  // work stack: a per-thread array on the host; the device never steps a game through this accessor
+  // work stack: a per-thread array on the host, large enough never to evict; the device never steps a game through
+  // this accessor
+#if defined(MSB_HOST_SKW)   // study / test build: the host evicts like the device does (oracle/Makefile libproduct_host_evict.so)
+  static constexpr int SKW = MSB_HOST_SKW;
+#else
+  static constexpr int SKW = SK_CAP;
+#endif
 #if !defined(__HIPCC__)
   MSB_HD MSB_INL static uint32_t sk_ld(int i) { return msb_host_wk[i]; }
-  MSB_HD MSB_INL static void sk_st(int i, uint32_t v) { msb_host_wk[i] = v; }
+  MSB_HD MSB_INL static void sk_st(int i, uint32_t v) {
+#if defined(MSB_HOST_SKW)
+    if (i >= SKW) __builtin_trap();   // a handler pushed more than SK_NEED words: the device would write past its LDS stack
+#endif
+    msb_host_wk[i] = v;
+  }
+  MSB_HD MSB_INL static uint32_t ovf_ld(int i) { return msb_host_ovf[i]; }
+  MSB_HD MSB_INL static void ovf_st(int i, uint32_t v) { msb_host_ovf[i] = v; }
 #else
   MSB_HD MSB_INL static uint32_t sk_ld(int) { return 0; }
   MSB_HD MSB_INL static void sk_st(int, uint32_t) {}
+  MSB_HD MSB_INL static uint32_t ovf_ld(int) { return 0; }
+  MSB_HD MSB_INL static void ovf_st(int, uint32_t) {}
 #endif
   // order in which abilities run (scenario tests): a log the host oracle can switch on; compiled out of device code
   MSB_HD MSB_INL static void trace_ability(int card, int pos) {
@@ -283,7 +302,7 @@ MSB_HD MSB_INL double lds_wtab(int age) {
   return g_wtab.v[age & AGE_MAX];
 }
 // call with all threads of the workgroup, before any engine code.  wk_ovf: this workgroup's overflow block of the work
-// stack (LANES * (SK_CAP - SKW) words, see LaneMem::sk_*), or null where no game is stepped
+// stack (LANES * SK_CAP words, see LaneMem::ovf_*), or null where no game is stepped
 MSB_HD MSB_INL void lds_init_wtab(uint32_t* wk_ovf = nullptr) {
   for (int i = (int)__builtin_amdgcn_workitem_id_x(); i < WT_LDS_N; i += (int)__builtin_amdgcn_workgroup_size_x())
     *(MSB_AS_LDS double*)(uintptr_t)(WT_LDS + 8 * i) = g_wtab.v[i];
@@ -300,23 +319,20 @@ MSB_HD MSB_INL void lds_init_wtab(uint32_t* wk_ovf = nullptr) {
 // empty object -- nothing has to be reloaded through `this` behind the non-inlined (recursive) calls of
 // the rules core, which cost a flat_load round trip per call when the accessor held a pointer.
 //
-// SKB / SKW: LDS address and words per lane of the work stack's resident part, interleaved across the lanes word by word
-// (word i of lane l at SKB + (i*LANES + l)*4); words SKW.. of a lane live in the workgroup's overflow block in HBM
+// SKB / SKW_: LDS address and words per lane of the work stack, interleaved across the lanes word by word (word i of
+// lane l at SKB + (i*LANES + l)*4).  ovf_*: word i of the lane's share of the workgroup's eviction block in HBM
 // (word-major as well: lanes at the same depth touch neighbouring words).
-template <int LANES, int BASE, int SKB = 0, int SKW = 0>
+template <int LANES, int BASE, int SKB = 0, int SKW_ = 0>
 struct LaneMem {   // this lane's private record among LANES interleaved ones
-  MSB_HD MSB_INL static uint32_t* sk_ovf(int i) {
+  static constexpr int SKW = SKW_;
+  MSB_HD MSB_INL static uint32_t* ovf(int i) {
     uint32_t* base = (uint32_t*)(uintptr_t)(*(MSB_AS_LDS const uint64_t*)(uintptr_t)WK_OVF_LDS);
-    return base + (size_t)(i - SKW) * LANES + (int)__builtin_amdgcn_workitem_id_x();
+    return base + (size_t)i * LANES + (int)__builtin_amdgcn_workitem_id_x();
   }
-  MSB_HD MSB_INL static uint32_t sk_ld(int i) {
-    if (i < SKW) return *(MSB_AS_LDS const uint32_t*)(uintptr_t)(SKB + (i * LANES + (int)__builtin_amdgcn_workitem_id_x()) * 4);
-    return *sk_ovf(i);
-  }
-  MSB_HD MSB_INL static void sk_st(int i, uint32_t v) {
-    if (i < SKW) *(MSB_AS_LDS uint32_t*)(uintptr_t)(SKB + (i * LANES + (int)__builtin_amdgcn_workitem_id_x()) * 4) = v;
-    else *sk_ovf(i) = v;
-  }
+  MSB_HD MSB_INL static uint32_t ovf_ld(int i) { return *ovf(i); }
+  MSB_HD MSB_INL static void ovf_st(int i, uint32_t v) { *ovf(i) = v; }
+  MSB_HD MSB_INL static uint32_t sk_ld(int i) { return *(MSB_AS_LDS const uint32_t*)(uintptr_t)(SKB + (i * LANES + (int)__builtin_amdgcn_workitem_id_x()) * 4); }
+  MSB_HD MSB_INL static void sk_st(int i, uint32_t v) { *(MSB_AS_LDS uint32_t*)(uintptr_t)(SKB + (i * LANES + (int)__builtin_amdgcn_workitem_id_x()) * 4) = v; }
   MSB_HD MSB_INL static MSB_AS_LDS uint8_t* b(int o) {
     return (MSB_AS_LDS uint8_t*)(uintptr_t)(BASE + (o >> 4) * (LANES * 16) + (o & 15) + (int)__builtin_amdgcn_workitem_id_x() * 16);
   }
@@ -392,8 +408,11 @@ struct SharedMem {   // one contiguous record read by every lane of the wave (LD
   MSB_HD MSB_INL static double wtab(int age) { return lds_wtab(age); }
   MSB_HD MSB_INL static void trace_ability(int, int) {}
   // the shared copy is only read (legal mask, features): nothing is ever stepped through it
+  static constexpr int SKW = SK_CAP;
   MSB_HD MSB_INL static uint32_t sk_ld(int) { return 0; }
   MSB_HD MSB_INL static void sk_st(int, uint32_t) {}
+  MSB_HD MSB_INL static uint32_t ovf_ld(int) { return 0; }
+  MSB_HD MSB_INL static void ovf_st(int, uint32_t) {}
 };
 #endif
 

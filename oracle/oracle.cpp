@@ -432,6 +432,9 @@ void orc_rng_shuffle(uint32_t seed, int k, int reps, int* out) {
     commit_rng(g, e);
   }
 }
+#if defined(MSB_COUNT_FRAMES)
+long long* orc_frame_counts() { return msb_frame_count; }   // study build (scripts/frame_stats.py)
+#endif
 int orc_pyset_list(const uint8_t* keys, int n, uint8_t* out) { return pyset_list(keys, n, out); }
 double orc_score(const double* w, const double* before, const double* after) {
   return Engine<FlatMem>::action_score(w, before, after);

@@ -42,12 +42,13 @@ def main():
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--must", default="")
     ap.add_argument("--max-steps", type=int, default=400)
+    ap.add_argument("--core", default="product", help="product | product_evict (host build with the device's 24-word resident stack)")
     a = ap.parse_args()
     rs = np.random.RandomState(a.seed)
     ids = pool_ids(a.pool, a.tier)
     must = [cards.CARD_IDS.index(x) for x in a.must.split(",") if x]
     A = oracle_lib.Oracle(1, extended=a.tier, core="oracle")
-    B = oracle_lib.Oracle(1, extended=a.tier, core="product")
+    B = oracle_lib.Oracle(1, extended=a.tier, core=a.core)
     w = np.random.RandomState(2024).uniform(0, 1, 10)
     steps = faults = 0
     t0 = time.time()

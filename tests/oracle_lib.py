@@ -16,6 +16,8 @@ LIB_PATH_BIG = os.path.join(ORACLE_DIR, "liboracle_big.so")   # large extended r
 # host builds of the PRODUCT's rules core (explicit work stack; oracle/oracle.cpp -DORC_PRODUCT_CORE): the same C entry
 # points over the other implementation of the rules, for the CPU-side checks of the product core
 PRODUCT_HOST = tuple(os.path.join(ORACLE_DIR, n) for n in ("libproduct_host.so", "libproduct_host_ext.so", "libproduct_host_big.so"))
+# ... and with the device's 24-word resident work stack, so that the eviction path of wk_reserve runs on the CPU too
+PRODUCT_HOST_EVICT = tuple(os.path.join(ORACLE_DIR, n) for n in ("libproduct_host_evict.so", "libproduct_host_evict_ext.so"))
 
 
 def build():
@@ -28,7 +30,7 @@ _libs = {}
 def lib(extended=False, core="oracle"):
     key = (extended, core)
     if key not in _libs:
-        paths = PRODUCT_HOST if core == "product" else (LIB_PATH, LIB_PATH_EXT, LIB_PATH_BIG)
+        paths = {"product": PRODUCT_HOST, "product_evict": PRODUCT_HOST_EVICT}.get(core, (LIB_PATH, LIB_PATH_EXT, LIB_PATH_BIG))
         path = extended if isinstance(extended, str) else paths[int(extended)]
         if not os.path.exists(path):
             build()
