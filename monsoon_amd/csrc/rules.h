@@ -189,6 +189,10 @@ constexpr int MAX_DEPTH = 40;
 // third batch (no gain, left out-of-line): shape_tiles +0.4 %, shuffle/sorted_head 0, legal_mask_v +0.2 %,
 // command/teleport/push_pull/force_attack/spawn/respawn +0.8 %; flip + to_next_turn inlined -8.5 %, ability_spell -18 %.
 // One non-inlined function per card instead of one switch function (abilities.inc): +3 %.
+// handlers of the rare frames, abilities with nested calls: out of line
+#ifndef MSB_A_RARE
+#define MSB_A_RARE MSB_NOINLINE
+#endif
 // leaf card abilities: one non-inlined function each (a call from run(), no call inside)
 #ifndef MSB_A_CARD
 #define MSB_A_CARD MSB_NOINLINE
@@ -2374,7 +2378,7 @@ struct Engine {
       k.result = (pl_base(remote()) <= 0 ? 1 : 0) | (have_winner() ? 2 : 0);
       m.st8(H_TOPLAY, lo ^ 1);
       flip();
-      call_next_turn(k);
+      k.sp = next_turn_out(k.sp);
     }
     run(k);
     if (fault()) return action == 155 ? k.result : 0;   // 0 if the play raised; what was computed before the turn was passed on otherwise
@@ -2403,12 +2407,36 @@ struct Engine {
       case F_CTXLEAVE: h_ctx_leave(k, hdr); break;
       case F_DESTROY_TAIL: h_destroy_tail(k, hdr); break;
       case F_CMD_TAIL: h_cmd_tail(k, hdr); break;
-      case F_EACH: h_each(k, hdr); break;
-      case F_AFTER: h_after(k, hdr); break;
-      case F_TURN: h_turn(k, hdr); break;
+      // the rare frames run out of line (MSB_A_RARE): their code stays out of the registers and the instruction stream
+      // of the two hot handlers
+      case F_EACH: k.sp = h_each_out(k.sp, k.base - k.seg, hdr); break;
+      case F_AFTER: k.sp = h_after_out(k.sp, k.base - k.seg, hdr); break;
+      case F_TURN: k.sp = h_turn_out(k.sp, k.base - k.seg, hdr); break;
       case F_EVICTED: h_evicted(k, hdr); break;
       default: set_fault(FAULT_UNSUPPORTED); break;   // not a frame: cannot happen
     }
+  }
+  // Out-of-line forms: the stack pointer goes in and comes back by value (a Wk passed by reference would live in memory);
+  // `deep` = words evicted - eviction marks, all wk_reserve needs.
+  MSB_HD MSB_A_RARE int h_each_out(int sp, int deep, uint32_t hdr) {
+    Wk k{sp, 0, deep, 0};
+    h_each(k, hdr);
+    return k.sp;
+  }
+  MSB_HD MSB_A_RARE int h_after_out(int sp, int deep, uint32_t hdr) {
+    Wk k{sp, 0, deep, 0};
+    h_after(k, hdr);
+    return k.sp;
+  }
+  MSB_HD MSB_A_RARE int h_turn_out(int sp, int deep, uint32_t hdr) {
+    Wk k{sp, 0, deep, 0};
+    h_turn(k, hdr);
+    return k.sp;
+  }
+  MSB_HD MSB_A_RARE int next_turn_out(int sp) {
+    Wk k{sp, 0, 0, 0};
+    call_next_turn(k);
+    return k.sp;
   }
   // Run the work stack until it is empty.  On the device the lanes of a wave are grouped by the function of their top
   // frame first (a "waterfall": take the first waiting lane's function as a wave-uniform value, serve the lanes
