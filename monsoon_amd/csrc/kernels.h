@@ -344,8 +344,12 @@ __device__ MSB_INL void play_game(const DevBuffers& b, const int g, const int la
       PROF_MARK(4);   // step
       if (active) {
         if (f == 0 && !before_raises && !raises) {
-          ce.features(cf);
-          s = CandEngine::action_score_lds(wf, cf);
+          // the ten values go to LDS for the winner's sake (argmax below) and feed the score from registers; they are
+          // dead before the shuffles, so they never sit in registers across them
+          double fa[10];
+          ce.features(fa);
+          for (int i = 0; i < 10; i++) cf[i] = fa[i];
+          s = CandEngine::action_score_lds(wf, fa);
           my_feat = 1;
         }
         if (write_scores) b.scores[(size_t)g * MONSOON_NUM_ACTIONS + a] = s;
@@ -380,8 +384,8 @@ __device__ MSB_INL void play_game(const DevBuffers& b, const int g, const int la
         wl = __ffsll((long long)bal) - 1;
         cfault = __builtin_amdgcn_readlane(my_fault, wl);
         feat_ok = __builtin_amdgcn_readlane(my_feat, wl);
-        if (lane == wl && my_feat)   // the winner keeps its features: the next decision's "before" side
-          for (int i = 0; i < 10; i++) wf[20 + i] = cf[i];
+        if (feat_ok && lane < 10)   // the winner keeps its features: the next decision's "before" side
+          wf[20 + lane] = ((MSB_AS_LDS const double*)(uintptr_t)L::CF)[wl * 10 + lane];
         if (multi) {
           __syncthreads();
           for (int c = lane; c < SG; c += 64) bestcol[c] = priv[c * U + wl];

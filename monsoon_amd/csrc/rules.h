@@ -666,6 +666,7 @@ struct Engine {
   }
   MSB_HD MSB_INL uint32_t empty_mask() const { return ~occ_mask() & 0xFFFFFu; }
   MSB_HD MSB_INL void begin_step() {
+    MSB_SCOPE(PS_BEGIN_STEP);
     // one shift per tile, no compare: an empty tile (0xFF) sets the top bit, which is not an entity slot
     static_assert((SLOT_NONE & 31) >= 28, "the empty marker must map outside the slot bits");
     Bits used = Bits::none();
@@ -1098,6 +1099,7 @@ struct Engine {
     return r_;
   }
   MSB_HD MSB_A_TARGETS PList get_targets_impl(int pov, Tgt t, int exclude_pk) {
+    MSB_SCOPE(PS_GET_TARGETS);
     PList out;
     out.clear();
     const bool asc = (pov == local());
@@ -1456,7 +1458,6 @@ struct Engine {
       const uint32_t w1 = m.sk_ld(top - 1);
       const int pos_pk = (int)((w1 >> 16) & 0xff);
       m.st8(H_RESOLVING, 1);
-      m.sk_st(top, hdr | (1u << 8));   // whatever the ability pushes, this frame resumes behind it
       if (e != 0xff) {
         M::trace_ability(e_card(e), m.ld8g(eg(e), EO_POS));   // diagnostics hook: nothing in the product
         ability_entity(k, e, pos_pk, src);
@@ -1465,7 +1466,11 @@ struct Engine {
         M::trace_ability(spell & 0xff, -1);
         ability_spell(k, spell & 0xff, spell >> 8, pos_pk);
       }
-      if (fault() || k.sp - 1 != top) return;   // raised, or still running (its frames are above this one)
+      if (fault()) return;
+      if (k.sp - 1 != top) {   // still running: its frames are above this one, which resumes behind them
+        m.sk_st(top, hdr | (1u << 8));
+        return;
+      }
     }
     // the ability has returned, card.py:54-60
     m.st8(H_RESOLVING, 0);
@@ -1604,6 +1609,7 @@ struct Engine {
     ctx_leave(sv);
   }
   MSB_HD MSB_A_SETPATH void set_path_impl(int e, bool on_play) {
+    MSB_SCOPE(PS_SET_PATH);
     P position = e_pos(e);
     int confused_cached = e_st(e, ST_CONFUSED);
     int owner = e_owner(e);
@@ -1692,19 +1698,16 @@ struct Engine {
     m.st8(H_DEPTH, d + 1);
     return d;
   }
+  // (a move's three data words hold nothing until it first waits for a nested call: only the header is written here)
   MSB_HD MSB_INL void call_move(Wk& k, int e, int played = 0) {
     const int d = move_enter(k, e);
     if (d < 0) return;
-    wk_push(k, 0);
-    wk_push(k, 0);
-    wk_push(k, 0);
+    k.sp += 3;
     wk_push(k, mk_hdr(F_MOVE, MV_ENTRY, e, d | played));
   }
   // a move that starts when the frames pushed after it have run
   MSB_HD MSB_INL void call_move_later(Wk& k, int e, int played) {
-    wk_push(k, 0);
-    wk_push(k, 0);
-    wk_push(k, 0);
+    k.sp += 3;
     wk_push(k, mk_hdr(F_MOVE, MV_START, e, played));
   }
   MSB_HD MSB_INL void h_move(Wk& k, uint32_t hdr) {
@@ -1716,20 +1719,19 @@ struct Engine {
       if (d0 < 0) return;
       k.sp += 4;
       hdr = mk_hdr(F_MOVE, MV_ENTRY, e0, d0 | played);
-      if (REM_LISTS) {   // the frame may have moved up by the world mark
-        m.sk_st(k.sp - 2, 0);
-        m.sk_st(k.sp - 3, 0);
-        m.sk_st(k.sp - 4, 0);
-      }
     }
     const int top = k.sp - 1;
     const int e = hdr_a(hdr), d = hdr_b(hdr) & 0x7f;
     const int played_tail = hdr_b(hdr) & MV_PLAYED;
-    uint32_t path = m.sk_ld(top - 1);
-    const uint32_t w2 = m.sk_ld(top - 2);
+    uint32_t path = 0, w2 = 0;
+    int cached = 0;
+    if (hdr_st(hdr) != MV_ENTRY) {   // a move that has waited: its locals
+      path = m.sk_ld(top - 1);
+      w2 = m.sk_ld(top - 2);
+      cached = (int)(int16_t)(m.sk_ld(top - 3) & 0xffffu);
+    }
     int i = (int)(w2 & 7), n = (int)((w2 >> 3) & 7), current_id = (int)((w2 >> 8) & 0xff), target = (int)((w2 >> 16) & 0xff);
     int flags = (int)(w2 >> 24);
-    int cached = (int)(int16_t)(m.sk_ld(top - 3) & 0xffffu);
     const int trig = e_trigger(e);
     int next = MV_DONE;
     P dest{0, 0};
@@ -2069,6 +2071,7 @@ struct Engine {
 
   // Player.draw, player.py:46-52: numpy choice(deck, size=1, p=w/sum(w))
   MSB_HD MSB_A_DRAW void draw(int o, int amount) {
+    MSB_SCOPE(PS_DRAW);
     for (int k = 0; k < amount; k++) {
       int n = pl_deck_n(o);
       if (n == 0) {
@@ -2136,6 +2139,7 @@ struct Engine {
   }
   // Player.play, player.py:68-77.  has_pos=false <=> position None
   MSB_HD MSB_INL void call_player_play(Wk& k, int o, int index, P position, bool has_pos) {
+    MSB_SCOPE(PS_PLAYER_PLAY);
     int card = hand_card(o, index), fl = hand_flags(o, index);
     int strength = inst_strength(card, fl, hand_x(o, index));   // target.copy() copies the instance's strength
     add_history(o, card);
@@ -2341,6 +2345,7 @@ struct Engine {
   // The caller guarantees `action` is in legal_actions().  Returns reward | done << 1 as the reference
   // computes them.  A play leaves frames for run(); so does passing the turn on, which has nothing before it.
   MSB_HD MSB_INL int step(int action) {
+    MSB_SCOPE(PS_STEP);
     Wk k{0, 0, 0, 0};
     begin_step();
     if (fault()) return 0;
@@ -2402,8 +2407,14 @@ struct Engine {
   }
   MSB_HD MSB_INL void wk_dispatch(Wk& k, int fn, const uint32_t hdr) {
     switch (fn) {
-      case F_MOVE: h_move(k, hdr); break;
-      case F_RUNAB: h_runab(k, hdr); break;
+      case F_MOVE: {
+        MSB_SCOPE(PS_MOVE);
+        h_move(k, hdr);
+      } break;
+      case F_RUNAB: {
+        MSB_SCOPE(PS_RUN_ABILITY);
+        h_runab(k, hdr);
+      } break;
       case F_CTXLEAVE: h_ctx_leave(k, hdr); break;
       case F_DESTROY_TAIL: h_destroy_tail(k, hdr); break;
       case F_CMD_TAIL: h_cmd_tail(k, hdr); break;
@@ -2419,6 +2430,7 @@ struct Engine {
   // Out-of-line forms: the stack pointer goes in and comes back by value (a Wk passed by reference would live in memory);
   // `deep` = words evicted - eviction marks, all wk_reserve needs.
   MSB_HD MSB_A_RARE int h_each_out(int sp, int deep, uint32_t hdr) {
+    MSB_SCOPE(PS_FORCE_ATTACK);
     Wk k{sp, 0, deep, 0};
     h_each(k, hdr);
     return k.sp;
@@ -2429,11 +2441,13 @@ struct Engine {
     return k.sp;
   }
   MSB_HD MSB_A_RARE int h_turn_out(int sp, int deep, uint32_t hdr) {
+    MSB_SCOPE(PS_NEXT_TURN);
     Wk k{sp, 0, deep, 0};
     h_turn(k, hdr);
     return k.sp;
   }
   MSB_HD MSB_A_RARE int next_turn_out(int sp) {
+    MSB_SCOPE(PS_FLIP);
     Wk k{sp, 0, 0, 0};
     call_next_turn(k);
     return k.sp;
@@ -2443,6 +2457,7 @@ struct Engine {
   // holding it, repeat), so the switch runs on a scalar and lanes that are in the same function -- whatever path of
   // calls took them there -- execute it together.
   MSB_HD MSB_INL void run(Wk& k) {
+    MSB_SCOPE(PS_COMMAND);   // profiling build: the whole loop (the handlers' own scopes are inside it)
     while (k.sp > 0 && !fault()) {
       uint32_t hdr = m.sk_ld(k.sp - 1);
       const int fn = hdr_fn(hdr);

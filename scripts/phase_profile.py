@@ -66,9 +66,11 @@ def main():
             print(f"  {name:16s} {cyc / dec:10.0f} cycles/decision {100 * cyc / tot:5.1f} %  {calls / dec:7.2f} calls/decision {cyc / calls:8.0f} cycles/call{extra}")
 
 
+# round 3 (work-stack core): "run() loop" = the whole dispatcher loop incl. handlers; "move" / "run_ability" = the F_MOVE / F_RUNAB
+# handlers; "F_EACH" / "F_TURN" / "next_turn prefix" the out-of-line ones
 SCOPES = ["step", "player_play", "new_entity", "run_ability", "ability_entity", "ability_spell", "get_targets", "shape_tiles",
-          "shape_targets", "deal_damage", "destroy", "front_line", "set_path", "move", "command", "force_attack", "draw",
-          "flip", "next_turn", "legal_mask", "shuffle", "sorted_head", "spawn", "respawn", "teleport", "push_pull", "empty_front",
+          "shape_targets", "deal_damage", "destroy", "front_line", "set_path", "move", "run() loop", "F_EACH", "draw",
+          "next_turn prefix", "F_TURN", "legal_mask", "shuffle", "sorted_head", "spawn", "respawn", "teleport", "push_pull", "empty_front",
           "begin_step", "obs_raises", "features"]
 
 
