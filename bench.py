@@ -9,17 +9,19 @@ One bench "step" = one pass of the hot path over the batch: every live game adva
 delta, score, argmax) + committing the chosen successor.  A game's record stays in LDS from its first to its last
 decision of the step; --rounds 1 is one decision round per launch (the round-1 form of this bench).
 
-Workload c4 (--workload c4; BASELINE.json configs[3]): population 1 024, 64 games per individual
-(ring schedule), deck S12 both sides, through FitnessEvaluator.evaluate_population -- the schedule is sharded by
-row individual over the ranks and the per-individual counters are summed with one all-reduce (RCCL).  Strong
-scaling: the 65 536 games of a generation are fixed, one step = one generation.
+Workloads c3 / c4 / c5 (--workload ...; BASELINE.json configs[2..4]): one generation of the GA's evaluation
+through FitnessEvaluator.evaluate_population per step -- c3: 256 individuals x 64 games on N12M; c4: population 1 024,
+64 games per individual on the Swarm deck S12; c5: population 4 096 x 128 games, per-game decks drawn on the device from
+the 109 observable cards, every game on the smallest record its decks need.  The schedule is sharded by row individual
+over the ranks and the per-individual counters are summed with one all-reduce (RCCL).  Strong scaling: the games of a
+generation are fixed; host time (schedule, decks, upload, collection) is inside the timed region.
 
 `value` counts the Stormbound.step transitions actually EXECUTED in the timed region (the look-ahead steps; the
 committed successor is one of them and is not re-executed) divided by the wall time of the region, summed over
 ranks / max over ranks.  Inputs are resident in HBM when the timed region starts (c2; c4 uploads 80 KB of weights
 and a 1 MB schedule per generation, as the GA driver does).
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2|c4|rollout] [--deck D] [--games G] [--lanes U] [--rounds R] [--no-cpu]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2|c3|c4|c5|rollout] [--deck D] [--games G] [--lanes U] [--rounds R] [--no-cpu]
 With --gpus N > 1 and no WORLD_SIZE in the environment this process starts the N ranks itself (one process per
 GPU through torch.distributed.run, before anything here touches a GPU) and relays rank 0's line; under
 torch.distributed.run it is one of the ranks.
@@ -49,13 +51,14 @@ METRIC = "env-steps/sec (whole node) at 65536 concurrent games; bit-exact vs CPU
 
 
 def recorded_traffic():
-    """HBM bytes per k_decide launch from the committed rocprofv3 PMC passes (profiles/traffic.json, written by
-    scripts/summarize_profile.py) with the configuration they were measured on -- an OFFLINE number, labelled so."""
+    """HBM bytes per k_play launch and the kernel's real ceilings (lanes per VALU instruction, VALU busy, wavefronts per
+    CU, scratch per lane) from the committed rocprofv3 PMC passes (profiles/traffic.json, written by
+    scripts/summarize_profile.py) with the configuration they were measured on -- OFFLINE numbers, labelled so."""
     p = os.path.join(REPO, "profiles", "traffic.json")
     if os.path.exists(p):
         d = json.load(open(p))
-        return d.get("bytes_per_launch"), d.get("measured_on", "profiles/traffic.json (separate rocprofv3 --pmc runs)")
-    return None, None
+        return d.get("bytes_per_launch"), d.get("measured_on", "profiles/traffic.json (separate rocprofv3 --pmc runs)"), d.get("ceilings")
+    return None, None, None
 
 
 def cpu_baseline(sample_games, max_turns, threads):
@@ -128,7 +131,7 @@ def parse_args(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=None)
     ap.add_argument("--warmup", type=int, default=None)
-    ap.add_argument("--workload", choices=["c2", "c4", "rollout"], default="c2")
+    ap.add_argument("--workload", choices=["c2", "c3", "c4", "c5", "rollout"], default="c2")
     ap.add_argument("--deck", default="N12M", help="rollout workload: a named deck (both sides), or 'random' = C5's per-game 12-card decks")
     ap.add_argument("--games", type=int, default=65536)
     ap.add_argument("--lanes", type=int, default=0, help="candidate lanes per game (0 = build default)")
@@ -139,7 +142,7 @@ def parse_args(argv=None):
     ap.add_argument("--cpu-threads", type=int, default=16)
     args = ap.parse_args(argv)
     if args.steps is None:
-        args.steps = 12 if args.workload == "c2" else 5
+        args.steps = 12 if args.workload == "c2" else (2 if args.workload == "c5" else 5)
     if args.warmup is None:
         args.warmup = 3 if args.workload == "c2" else 1
     return args
@@ -216,7 +219,7 @@ def run_rank(args):
     elif args.workload == "rollout":
         line = bench_rollout(args, rank, world, local_rank, barrier, all_sum, all_max)
     else:
-        line = bench_c4(args, rank, world, local_rank, barrier, all_sum, all_max)
+        line = bench_ga(args, rank, world, local_rank, barrier, all_sum, all_max)
     # ranks that really took part in the collective (the job's size as RCCL saw it)
     took_part = int(all_sum([1])[0])
     if rank == 0:
@@ -274,7 +277,10 @@ def bench_c2(args, rank, world, local_rank, fake, barrier, all_sum, all_max):
     avg_launch_s = (kms / 1000.0) / max(launches, 1)
     alg_bytes = (BYTES_LOOKAHEAD * look + BYTES_COMMIT * dec) / max(launches, 1)
     achieved = alg_bytes / avg_launch_s / 1e9 if avg_launch_s > 0 else 0.0
-    traffic, traffic_on = recorded_traffic()
+    traffic, traffic_on, ceilings = recorded_traffic()
+    # what the kernel has to move at the least: every game's record and meta row in and out once per launch (the RNG
+    # words it draws and the block refills come on top; SURVEY's per-step figure assumes a record read per look-ahead)
+    physical = float(n) * 2 * (832 + 32)
     line = {
         "metric": METRIC,
         "value": tot_look / max_dt,
@@ -299,8 +305,10 @@ def bench_c2(args, rank, world, local_rank, fake, barrier, all_sum, all_max):
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_measured_on": traffic_on,
                      "kernel": "k_play", "avg_launch_ms": 1000.0 * avg_launch_s, "launches": launches,
-                     "algorithmic_bytes_per_launch": alg_bytes},
+                     "algorithmic_bytes_per_launch": alg_bytes, "physical_bytes_per_launch": physical},
     }
+    if ceilings:   # offline, from the same rocprofv3 passes as `traffic`: the ceilings that bind this integer, LDS-resident kernel
+        line["roofline"].update(ceilings)
     if not args.no_cpu and world == 1 and rank == 0 and not fake:
         line["cpu_baseline"] = cpu_baseline(args.cpu_sample, 200, args.cpu_threads)
     return line
@@ -364,13 +372,24 @@ def bench_rollout(args, rank, world, local_rank, barrier, all_sum, all_max):
     }
 
 
-def bench_c4(args, rank, world, local_rank, barrier, all_sum, all_max):
-    """Strong scaling: one generation of N = 1 024 individuals x 64 ring games on the S12 deck per step."""
+GA_WORKLOADS = {
+    # name: (individuals evaluated per generation, games per individual, deck, what BASELINE.json calls it)
+    "c3": (256, 64, "N12M", "C3: mu = lambda = 128 (256 evaluated individuals) x 64 ring games per generation (16384 games), N12M deck both sides"),
+    "c4": (1024, 64, "S12", "C4: population 1024 x 64 ring games per generation (65536 games), S12 deck both sides"),
+    "c5": (4096, 128, "random109", "C5: population 4096 x 128 ring games per generation (524288 games), per-game decks drawn on the device "
+                                   "from the 109 observable cards, every game on the smallest record its decks need"),
+}
+
+
+def bench_ga(args, rank, world, local_rank, barrier, all_sum, all_max):
+    """Strong scaling: one step = one generation of the named configuration through FitnessEvaluator.evaluate_population --
+    schedule, per-game decks (c5: monsoon_draw_decks), upload, rollouts, collection and the all-reduce of the counters are
+    all inside the timed region; the schedule is sharded by row individual over the ranks."""
     from monsoon_amd.config import EvolutionaryConfig
     from monsoon_amd.fitness import FitnessEvaluator
     from monsoon_amd.weights import WeightVector
-    n_ind, gpi = 1024, 64
-    cfg = EvolutionaryConfig(mu=n_ind, lambda_=n_ind, schedule="ring", games_per_individual=gpi, deck="S12", max_turns=200,
+    n_ind, gpi, deck, what = GA_WORKLOADS[args.workload]
+    cfg = EvolutionaryConfig(mu=n_ind, lambda_=n_ind, schedule="ring", games_per_individual=gpi, deck=deck, max_turns=200,
                              max_concurrent_games=65536, lanes_per_game=args.lanes)
     np.random.seed(42)
     pop = [WeightVector(10) for _ in range(n_ind)]
@@ -379,14 +398,18 @@ def bench_c4(args, rank, world, local_rank, barrier, all_sum, all_max):
     for g in range(args.warmup):
         ev.evaluate_population(pop, generation=g)
     ev.reset_stats()
+    ev.tier_games, ev.capacity_replays, ev.capacity_faults = [0, 0], 0, 0
     barrier()
     t0 = time.perf_counter()
     for g in range(args.steps):
         fit = ev.evaluate_population(pop, generation=100 + g)   # includes the all-reduce of the counters
     barrier()
     dt = time.perf_counter() - t0
-    tot_steps = all_sum([ev.total_env_steps])[0]
+    kms, launches = ev.kernel_time()
+    tot_steps, tot_dec = all_sum([ev.total_env_steps, ev.total_decisions])
     max_dt = all_max(dt)
+    alg = BYTES_LOOKAHEAD * ev.total_env_steps + BYTES_COMMIT * ev.total_decisions
+    achieved = alg / max(kms / 1000.0, 1e-9) / 1e9
     return {
         "metric": METRIC,
         "value": tot_steps / max_dt,
@@ -400,11 +423,16 @@ def bench_c4(args, rank, world, local_rank, barrier, all_sum, all_max):
         "vs_baseline": None,
         "dtype": "u8/i16 state, f64 draw+score",
         "data": "synthetic",
-        "config": {"workload": "C4: population 1024 x 64 ring games per generation (65536 games), S12 deck both sides, "
-                               "FitnessEvaluator.evaluate_population, schedule sharded by row individual",
-                   "games_per_step": n_ind * gpi, "parallelism": f"row individuals sharded x{world}, one all-reduce of int64[1024][3]"},
+        "config": {"workload": what + ", FitnessEvaluator.evaluate_population, schedule sharded by row individual",
+                   "games_per_step": n_ind * gpi, "parallelism": f"row individuals sharded x{world}, one all-reduce of int64[{n_ind}][3]"},
         "games_per_s": n_ind * gpi * args.steps / max_dt,
+        "decisions_per_s": tot_dec / max_dt,
         "mean_fitness": float(np.mean(fit)),
+        "record_tiers": {"standard": ev.tier_games[0], "extended": ev.tier_games[1], "replayed_on_a_larger_record": ev.capacity_replays,
+                         "left_on_a_record_limit": ev.capacity_faults},
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "kernel": "k_play (rank 0, all record tiers)", "kernel_ms_per_step": kms / max(args.steps, 1), "launches": launches,
+                     "host_and_other_ms_per_step": 1000.0 * dt / args.steps - kms / max(args.steps, 1)},
     }
 
 

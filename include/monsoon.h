@@ -166,6 +166,13 @@ int monsoon_rollout(monsoon_t* h, const double* weights, int32_t n_individuals, 
  * libmonsoon_hip_big.so, as monsoon_amd/fitness.py does -- and their rows of the result replaced. */
 int monsoon_rollout_faults(monsoon_t* h, uint8_t* out, int32_t n_matches);
 
+/* Per-game decks of configuration C5 on the device: for every seed, numpy.random.RandomState(seed).choice(pool, 12,
+ * replace=False) twice -> out_pairs[n][2][12] (card indices taken from pool[pool_n], 12 <= pool_n <= 128).  The caller
+ * passes the pre-stream seeds (game seed ^ 0x9E3779B9).  Host buffers in and out; needs no loaded games.
+ * Replaces the per-game Python draw of games/evolutionary_stormbound.py:52 + utils.py:26-119 for this configuration
+ * (150 us per game in numpy, 79 s for one C5 generation). */
+int monsoon_draw_decks(monsoon_t* h, const uint32_t* seeds, int32_t n, const uint8_t* pool, int32_t pool_n, uint8_t* out_pairs);
+
 /* Diagnostics: 192 raw counter words (words 0-4 back monsoon_get_stats; a profiling build (-DMSB_PROF=1,
  * scripts only) adds k_decide phase cycles at 8..15, per-function cycles / calls at 32..63 / 64..95, last-launch
  * occupancy at 96..101 and call entry / exit cycles at 128..159 / 160..191; the rest is zero).
@@ -186,10 +193,9 @@ int monsoon_get_stats(monsoon_t* h, monsoon_stats* out);
 int monsoon_reset_stats(monsoon_t* h);
 /* HIP-event timing of the decide kernel since the last reset_stats: total ms and launch count. */
 int monsoon_kernel_time(monsoon_t* h, double* total_ms, int64_t* launches);
-/* The stream the handle launches on (hipStream_t) so a caller can order its own work; NULL-safe.  By default this is the
- * device's default stream (returned as NULL) for every handle of every build: the kernels keep a per-lane stack in
- * scratch memory, and two hardware queues that both hold scratch make the runtime move it between them at every launch
- * (hundreds of ms).  MONSOON_OWN_STREAM=1 in the environment gives each handle a stream of its own again. */
+/* The stream the handle launches on (hipStream_t) so a caller can order its own work; NULL-safe.  Every handle has a
+ * stream of its own (one handle = one device + one stream; independent handles are independent).  MONSOON_OWN_STREAM=0
+ * in the environment puts all handles on the device's default stream (returned as NULL), as round 2 had to. */
 void* monsoon_stream(monsoon_t* h);
 
 #ifdef __cplusplus

@@ -51,3 +51,31 @@ def needs_extended(decks):
     """True if any deck (ids or indices) holds a card that only the extended build supports."""
     idx = {CARD_INDEX[c] for c in NEEDS_EXTENDED}
     return any((CARD_INDEX[c] if isinstance(c, str) else int(c)) in idx for c in np.asarray(decks, dtype=object).ravel())
+
+
+def needs_extended_each(deck_pairs):
+    """bool[n]: which deck pairs [n][2][12] (card indices) hold a card that only the extended build supports."""
+    pairs = np.asarray(deck_pairs, dtype=np.uint8).reshape(-1, 24)
+    idx = np.array(sorted(CARD_INDEX[c] for c in NEEDS_EXTENDED), dtype=np.uint8)
+    return np.isin(pairs, idx).any(axis=1)
+
+
+# Configuration C5 (SURVEY.md §8d): every game draws its two decks from the 109 observable cards -- every card but
+# up01/up02/up03, whose int(card) raises (card.py:46) and would end half of the games before their first step -- with a
+# pre-stream of its own: RandomState(seed ^ C5_STREAM_XOR).choice(pool, 12, replace=False), P1's deck first.
+RANDOM_DECK = "random109"
+C5_STREAM_XOR = 0x9E3779B9
+
+
+def observable_pool():
+    return np.array([i for i, c in enumerate(CARD_IDS) if c not in FAULT_CARDS], dtype=np.uint8)
+
+
+def draw_random_decks_numpy(seeds, pool=None):
+    """The specification of monsoon_draw_decks, by numpy itself (150 us per game: tests and small schedules only)."""
+    pool = observable_pool() if pool is None else np.asarray(pool, dtype=np.uint8)
+    out = np.zeros((len(seeds), 2, 12), dtype=np.uint8)
+    for k, s in enumerate(seeds):
+        rs = np.random.RandomState(int(s))
+        out[k, 0], out[k, 1] = rs.choice(pool, 12, replace=False), rs.choice(pool, 12, replace=False)
+    return out

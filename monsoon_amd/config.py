@@ -41,7 +41,7 @@ class EvolutionaryConfig:
     mode: str = "rollout"            # "rollout" = corrected loop; "as_written" = reference bug-for-bug
     schedule: str = "round_robin"    # "round_robin" (evo/fitness.py:53-59) or "ring" 
     games_per_individual: int = 64   # ring schedule only
-    deck: str = "N12M"               # key of monsoon_amd.cards.DECKS, both sides
+    deck: str = "N12M"               # key of monsoon_amd.cards.DECKS, both sides; "random109" = per-game decks of configuration C5 (cards.RANDOM_DECK)
     max_concurrent_games: int = 65536
     lanes_per_game: int = 0          # hot-kernel variant: candidate lanes per game (0 = build default)
 

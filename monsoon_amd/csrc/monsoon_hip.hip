@@ -406,6 +406,63 @@ __global__ void k_blob(DevBuffers b, int g, uint32_t* blob, int load) {
   }
 }
 
+// monsoon_draw_decks: numpy.random.RandomState(seed).choice(pool, 12, replace=False), twice, for every seed -- the
+// per-game decks of configuration C5 (two draws from a pre-stream of the game's own, seeded with
+// seed ^ 0x9E3779B9 by the caller).  Legacy choice without replacement is permutation(len(pool))[:12] (numpy
+// mtrand.pyx: choice -> permutation -> shuffle -> _shuffle_raw): a Fisher-Yates shuffle of arange(len(pool)) from the top
+// down with j = random_interval(i) (masked rejection, mt19937.h / Appendix C), the same shuffle Player.__init__ applies
+// to a deck (player.py:28).  One wavefront per seed: init_genrand is a serial recurrence (lane 0), the two twists that
+// yield the first 1 248 outputs are wave-cooperative, the 2 x (len(pool) - 1) draws serial again.  A seed whose draws
+// need more than 1 248 outputs (expected: 270) is reported, never truncated.
+__global__ void __launch_bounds__(64) k_draw_decks(int n, const uint32_t* seeds, const uint8_t* pool, int pool_n, uint8_t* out, int* overrun) {
+  __shared__ uint32_t mt[MT_N];
+  __shared__ uint32_t words[2 * MT_N];
+  __shared__ uint8_t perm[128];
+  const int lane = threadIdx.x, g = blockIdx.x;
+  if (g >= n) return;
+  MSB_AS_LDS uint32_t* t = (MSB_AS_LDS uint32_t*)mt;
+  if (lane == 0) {
+    uint32_t x = seeds[g];
+    t[0] = x;
+    for (int i = 1; i < MT_N; i++) {
+      x = 1812433253u * (x ^ (x >> 30)) + (uint32_t)i;
+      t[i] = x;
+    }
+  }
+  __syncthreads();
+  for (int blk = 0; blk < 2; blk++) {
+    wave_twist_lds(t, lane);
+    for (int k = lane; k < MT_N; k += 64) words[blk * MT_N + k] = mt_temper(t[k]);
+    __syncthreads();
+  }
+  if (lane != 0) return;
+  int pos = 0;
+  bool over = false;
+  for (int side = 0; side < 2; side++) {
+    for (int i = 0; i < pool_n; i++) perm[i] = (uint8_t)i;
+    for (int i = pool_n - 1; i >= 1; i--) {
+      uint32_t mask = (uint32_t)i;
+      mask |= mask >> 1;
+      mask |= mask >> 2;
+      mask |= mask >> 4;
+      uint32_t v = 0;
+      do {
+        if (pos >= 2 * MT_N) {
+          over = true;
+          v = 0;
+          break;
+        }
+        v = words[pos++] & mask;
+      } while (v > (uint32_t)i);
+      uint8_t tmp = perm[i];
+      perm[i] = perm[v];
+      perm[v] = tmp;
+    }
+    for (int k = 0; k < 12; k++) out[(size_t)g * 24 + side * 12 + k] = pool[perm[k]];
+  }
+  if (over) atomicAdd(overrun, 1);
+}
+
 }  // namespace
 
 // ================================================================================================
@@ -542,14 +599,14 @@ static hipError_t bind_device(monsoon_t* h);
 static int create_impl(monsoon* h) {
   const monsoon_config& cfg = h->cfg;
   size_t cap = (size_t)cfg.max_games;
-  // the rules core recurses (move -> ability -> ...): every lane gets a scratch stack (device-wide limit, only ever raised)
   HIP_TRY(h, bind_device(h));
-  // Every handle of every build runs on the device's DEFAULT stream unless MONSOON_OWN_STREAM=1 asks for a stream per handle.
-  // The kernels need a per-lane stack (16-32 KiB x 64 lanes x resident waves = GBs of scratch per hardware queue); with two
-  // queues holding scratch (a standard and an extended handle alive, say) the runtime hands the scratch back and forth
-  // and EVERY k_play launch costs 200-500 ms instead of 0.2 ms (measured, scripts/probe/launch_cost2.py).  One queue, one
-  // scratch allocation: nothing to reclaim.
-  if (getenv("MONSOON_OWN_STREAM") && atoi(getenv("MONSOON_OWN_STREAM")) != 0) {
+  // One stream per handle: independent handles do not serialise against each other or against the other blocking
+  // streams of the process (a torch consumer of the observation tensor, say).  Round 2 had to put every handle on the
+  // device's default stream: its kernels kept a 16-32 KiB per-lane stack in scratch memory and two hardware queues
+  // holding GBs of scratch made the runtime hand it back and forth (200-500 ms per launch).  The rules core has no
+  // stack in scratch any more (< 1 KiB of spill slots per lane): three builds alive on three streams launch in
+  // 0.15-0.4 ms (scripts/probe/own_stream.py, profiles/r03_own_stream.txt).  MONSOON_OWN_STREAM=0 = the default stream.
+  if (!getenv("MONSOON_OWN_STREAM") || atoi(getenv("MONSOON_OWN_STREAM")) != 0) {
     HIP_TRY(h, hipStreamCreate(&h->stream));
     h->own_stream = true;
   } else {
@@ -705,6 +762,56 @@ int monsoon_reset(monsoon_t* h, int32_t n, const uint32_t* seeds, const uint8_t*
   HIP_TRY(h, hipStreamSynchronize(h->stream));
   h->n = n;
   return MONSOON_OK;
+}
+
+int monsoon_draw_decks(monsoon_t* h, const uint32_t* seeds, int32_t n, const uint8_t* pool, int32_t pool_n, uint8_t* out_pairs) {
+  if (!h || !seeds || !pool || !out_pairs || n <= 0 || pool_n < 12 || pool_n > 128) {
+    if (h) h->err = "monsoon_draw_decks: bad argument (12 <= pool_n <= 128)";
+    return MONSOON_ERR_ARG;
+  }
+  for (int i = 0; i < pool_n; i++)
+    if (pool[i] >= NUM_CARDS) {
+      h->err = "monsoon_draw_decks: pool entry " + std::to_string(i) + " is not a card index";
+      return MONSOON_ERR_ARG;
+    }
+  HIP_TRY(h, bind_device(h));
+  uint32_t* d_seeds = nullptr;
+  uint8_t *d_pool = nullptr, *d_out = nullptr;
+  int* d_over = nullptr;
+  auto done = [&](int rc) {
+    hipFree(d_seeds);
+    hipFree(d_pool);
+    hipFree(d_out);
+    hipFree(d_over);
+    return rc;
+  };
+#define DD_TRY(call)                                                  \
+  do {                                                                \
+    hipError_t e_ = (call);                                           \
+    if (e_ != hipSuccess) {                                           \
+      h->err = std::string(#call) + ": " + hipGetErrorString(e_);     \
+      return done(MONSOON_ERR_DEVICE);                                \
+    }                                                                 \
+  } while (0)
+  DD_TRY(hipMalloc(&d_seeds, (size_t)n * 4));
+  DD_TRY(hipMalloc(&d_pool, 128));
+  DD_TRY(hipMalloc(&d_out, (size_t)n * 24));
+  DD_TRY(hipMalloc(&d_over, 4));
+  DD_TRY(hipMemcpyAsync(d_seeds, seeds, (size_t)n * 4, hipMemcpyHostToDevice, h->stream));
+  DD_TRY(hipMemcpyAsync(d_pool, pool, (size_t)pool_n, hipMemcpyHostToDevice, h->stream));
+  DD_TRY(hipMemsetAsync(d_over, 0, 4, h->stream));
+  hipLaunchKernelGGL(k_draw_decks, dim3(n), dim3(64), 0, h->stream, n, d_seeds, d_pool, pool_n, d_out, d_over);
+  DD_TRY(hipGetLastError());
+  int over = 0;
+  DD_TRY(hipMemcpyAsync(out_pairs, d_out, (size_t)n * 24, hipMemcpyDeviceToHost, h->stream));
+  DD_TRY(hipMemcpyAsync(&over, d_over, 4, hipMemcpyDeviceToHost, h->stream));
+  DD_TRY(hipStreamSynchronize(h->stream));
+#undef DD_TRY
+  if (over) {
+    h->err = "monsoon_draw_decks: " + std::to_string(over) + " seed(s) needed more than 1248 outputs of their stream";
+    return done(MONSOON_ERR_STATE);
+  }
+  return done(MONSOON_OK);
 }
 
 int monsoon_legal_mask(monsoon_t* h, uint64_t* out) {

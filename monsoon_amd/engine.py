@@ -221,6 +221,16 @@ class BatchEngine:
         self._ck(self.lib.monsoon_rollout_faults(self.h, _ptr(out), n_matches), "monsoon_rollout_faults")
         return out
 
+    def draw_decks(self, seeds, pool):
+        """uint8[n][2][12]: RandomState(seed).choice(pool, 12, replace=False) twice per seed, drawn on the device
+        (monsoon_draw_decks; configuration C5's per-game decks)."""
+        seeds = np.ascontiguousarray(seeds, dtype=np.uint32)
+        pool = np.ascontiguousarray(pool, dtype=np.uint8)
+        out = np.zeros((len(seeds), 2, 12), dtype=np.uint8)
+        if len(seeds):
+            self._ck(self.lib.monsoon_draw_decks(self.h, _ptr(seeds), len(seeds), _ptr(pool), len(pool), _ptr(out)), "monsoon_draw_decks")
+        return out
+
     # ---- device-resident rounds (bench) -------------------------------------------------------
     def upload_weights(self, weights):
         weights = np.ascontiguousarray(weights, dtype=np.float64).reshape(-1, 10)

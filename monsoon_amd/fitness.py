@@ -100,54 +100,104 @@ def replace_capacity_faulted(counts, results, steps, faults, matches, replay):
     return len(bad)
 
 
+def tiered_rollout(play, n_rows, matches, deck_pairs):
+    """A schedule played on the smallest record each game needs.  play(tier, sub_matches, sub_deck_pairs) ->
+    (counts[n_rows][3], results, steps, faults) runs matches on one build (tier 0 standard, 1 extended, 2 large record);
+    it is handed only the deck pairs its matches name (a build refuses a table holding a card it does not support).
+
+    Tier per GAME, not per call: only a deck pair holding ua20 / b005 needs the extended record (4 240 bytes against
+    832: the hot kernel runs half as many wavefronts with half as many candidate lanes on it), so a schedule of random
+    109-card decks -- 37 % of whose games hold one of the two -- is split in two sub-schedules.  Then the ladder: games
+    that hit a limit of their record (fault code >= 16) are played again on the next larger one and their rows replaced
+    (nested b005 memories are deep copies of the whole game, cards/b005.py:14-33, card.py:71-75: the reference's copies
+    nest without bound, a record does not).  Returns (counts, results, steps, faults, replays, tier_sizes)."""
+    from .cards import needs_extended_each
+    matches = np.asarray(matches)
+    deck_pairs = np.asarray(deck_pairs, dtype=np.uint8).reshape(-1, 2, 12)
+    ext_pair = needs_extended_each(deck_pairs)
+
+    def run(t, sub):
+        used, inv = np.unique(sub["deck"], return_inverse=True)
+        sub = sub.copy()
+        sub["deck"] = inv
+        return play(t, sub, deck_pairs[used])
+    tier = ext_pair[matches["deck"]].astype(np.int8) if len(ext_pair) > 1 else np.full(len(matches), int(ext_pair[0]), dtype=np.int8)
+    counts = np.zeros((n_rows, 3), dtype=np.int64)
+    results = np.zeros(len(matches), dtype=np.int8)
+    steps = np.zeros(len(matches), dtype=np.int32)
+    faults = np.zeros(len(matches), dtype=np.uint8)
+    sizes = []
+    for t in (0, 1):
+        idx = np.nonzero(tier == t)[0]
+        sizes.append(len(idx))
+        if not len(idx):
+            continue
+        c, r, s_, f = run(t, matches[idx])
+        counts += np.asarray(c, dtype=np.int64)
+        results[idx], steps[idx], faults[idx] = r, s_, f
+    replays = 0
+    for t in (1, 2):   # standard -> extended -> large
+        bad = np.nonzero((faults >= CAPACITY_CODE) & (tier < t))[0]
+        if not len(bad):
+            continue
+        replays += len(bad)
+        c2, r2, s2, f2 = run(t, matches[bad])
+        p1 = matches["p1"][bad]
+        np.subtract.at(counts[:, 0], p1, results[bad] == 0)
+        np.subtract.at(counts[:, 1], p1, results[bad] == -1)
+        np.subtract.at(counts[:, 2], p1, 1)
+        counts += np.asarray(c2, dtype=np.int64)
+        results[bad], steps[bad], faults[bad] = r2, s2, f2
+        tier[bad] = t
+    return counts, results, steps, faults, replays, sizes
+
+
 class FitnessEvaluator:
-    def __init__(self, config, deck_config=None, rollout_fn=None, device=None):
+    def __init__(self, config, deck_config=None, rollout_fn=None, device=None, deck_draw_fn=None):
         self.config = config
         self.deck_config = deck_config      # monsoon_amd.decks.DeckEvolutionConfig (utils.py:121-242) or None = config.deck both sides
         self.total_games = 0
         self.total_time = 0.0
         self.total_env_steps = 0
+        self.total_decisions = 0
         self.hall_of_fame = []
         self.hall_of_fame_size = 5
         self.use_hall_of_fame = True
         self._rollout_fn = rollout_fn
+        self._deck_draw_fn = deck_draw_fn   # test hook like rollout_fn: (pre-stream seeds, pool) -> uint8[n][2][12]
         self._device = device
         self._engines = {}
         self.eval_times = []            # wall seconds of every evaluate_population call (the first one creates the engine)
         self.capacity_replays = 0       # games replayed on the large record
         self.capacity_faults = 0        # games not even the large record could hold (their fault code ends them as draws)
+        self.tier_games = [0, 0]        # games first played on the standard / the extended record
 
     # -- device ------------------------------------------------------------------------------
-    def _hip_rollout(self, weights, matches, deck_pairs, max_turns):
-        from .cards import needs_extended
+    def _engine(self, tier):
         from .engine import BatchEngine
-        ext = int(bool(needs_extended(deck_pairs)))   # ua20 / b005 only run on the extended-record build
+        if self._engines.get(tier) is None:
+            dev = self._device
+            if dev is None:
+                import os
+                dev = int(os.environ.get("LOCAL_RANK", "0"))
+            # the large record is a replay tier for a few games per thousand: a small handle, its default variant
+            games = self.config.max_concurrent_games if tier < 2 else min(self.config.max_concurrent_games, 2048)
+            self._engines[tier] = BatchEngine(games, device=dev, lanes_per_game=self.config.lanes_per_game if tier == 0 else 0, extended=tier)
+        return self._engines[tier]
 
-        def engine(tier):
-            if self._engines.get(tier) is None:
-                dev = self._device
-                if dev is None:
-                    import os
-                    dev = int(os.environ.get("LOCAL_RANK", "0"))
-                # the large record is a replay tier for a few games per thousand: a small handle, its default variant
-                games = self.config.max_concurrent_games if tier < 2 else min(self.config.max_concurrent_games, 2048)
-                self._engines[tier] = BatchEngine(games, device=dev, lanes_per_game=self.config.lanes_per_game if tier < 2 else 0, extended=tier)
-            return self._engines[tier]
-
-        def play(tier, sub):
-            eng = engine(tier)
+    def _hip_rollout(self, weights, matches, deck_pairs, max_turns):
+        def play(tier, sub, sub_pairs):
+            eng = self._engine(tier)
             before = eng.stats()["lookahead_steps"]
-            counts, results, steps = eng.rollout(weights, sub, deck_pairs, max_turns, want_results=True)
+            counts, results, steps = eng.rollout(weights, sub, sub_pairs, max_turns, want_results=True)
             self.total_env_steps += eng.stats()["lookahead_steps"] - before
+            self.total_decisions += int(steps.sum())
             return counts.astype(np.int64), results, steps, eng.rollout_faults(len(sub))
 
-        counts, results, steps, faults = play(ext, matches)
-        # nested b005 memories are deep copies of the whole game (cards/b005.py:14-33, card.py:71-75): the few games whose
-        # copies outgrow the extended record (128 entity slots) are replayed on the large one (254).  The standard
-        # record (28 slots) has never been seen to overflow; if it did, the same ladder applies: standard -> extended -> large.
-        for tier in range(ext + 1, 3):
-            self.capacity_replays += replace_capacity_faulted(counts, results, steps, faults, matches, lambda sub, t=tier: play(t, sub))
+        counts, results, steps, faults, replays, sizes = tiered_rollout(play, len(weights), matches, deck_pairs)
+        self.capacity_replays += replays
         self.capacity_faults += int((faults >= CAPACITY_CODE).sum())
+        self.tier_games = [a + b for a, b in zip(self.tier_games, sizes)]
         self.last_rollout = (results, steps, faults)
         return counts
 
@@ -155,7 +205,16 @@ class FitnessEvaluator:
         """Deck pairs [n_decks][2][12] for a schedule; fills matches["deck"].  Without a deck_config: config.deck both
         sides.  With one: utils.py:155-219 per GAME, as games/evolutionary_stormbound.py:52 draws them (one pair for
         the whole generation while the schedule is in its exploit phase)."""
-        from .cards import deck_indices
+        from .cards import C5_STREAM_XOR, RANDOM_DECK, deck_indices, draw_random_decks_numpy, observable_pool
+        if self.deck_config is None and self.config.deck == RANDOM_DECK:
+            # configuration C5: two decks per game from the 109 observable cards, drawn by the game's own pre-stream
+            pre = matches["seed"] ^ np.uint32(C5_STREAM_XOR)
+            matches["deck"] = np.arange(len(matches))
+            if self._deck_draw_fn is not None:
+                return self._deck_draw_fn(pre, observable_pool())
+            if self._rollout_fn is not None:   # CPU stand-in (tests): numpy itself
+                return draw_random_decks_numpy(pre)
+            return self._engine(0).draw_decks(pre, observable_pool())
         if self.deck_config is None:
             deck = deck_indices(self.config.deck)
             return np.stack([deck, deck])[None]
@@ -202,15 +261,22 @@ class FitnessEvaluator:
             np.add.at(counts[:, 2], matches["p1"], 1)
         else:
             weights = np.stack([np.asarray(o.weights, dtype=np.float64) for o in opponents])
-            deck_pairs = self._decks_for(matches, generation)   # drawn for the WHOLE schedule, so every rank sees the same decks
+            from .cards import RANDOM_DECK
             dist = self._dist()
             mine = matches
-            if dist is not None:
-                mine = shard_by_individual(matches, n, dist.get_rank(), dist.get_world_size())
-                if len(deck_pairs) > 1 and len(mine):   # keep only this rank's decks
-                    deck_pairs = deck_pairs[mine["deck"]]
-                    mine = mine.copy()
-                    mine["deck"] = np.arange(len(mine))
+            if self.deck_config is None and cfg.deck == RANDOM_DECK:
+                # per-game decks that depend on the game's seed alone: every rank draws only the games it plays
+                if dist is not None:
+                    mine = shard_by_individual(matches, n, dist.get_rank(), dist.get_world_size()).copy()
+                deck_pairs = self._decks_for(mine, generation) if len(mine) else np.zeros((1, 2, 12), dtype=np.uint8)
+            else:
+                deck_pairs = self._decks_for(matches, generation)   # a sequential stream (utils.py:155-219): drawn for the WHOLE schedule, so every rank sees the same decks
+                if dist is not None:
+                    mine = shard_by_individual(matches, n, dist.get_rank(), dist.get_world_size())
+                    if len(deck_pairs) > 1 and len(mine):   # keep only this rank's decks
+                        deck_pairs = deck_pairs[mine["deck"]]
+                        mine = mine.copy()
+                        mine["deck"] = np.arange(len(mine))
             fn = self._rollout_fn or self._hip_rollout
             counts = np.zeros((n_total, 3), dtype=np.int64)
             if len(mine):
@@ -245,7 +311,20 @@ class FitnessEvaluator:
                 "env_steps": self.total_env_steps, "capacity_replays": self.capacity_replays, "capacity_faults": self.capacity_faults,
                 "env_steps_per_second": self.total_env_steps / max(self.total_time, 1e-6)}
 
+    def kernel_time(self):
+        """(ms, launches) of the hot kernel over every engine this evaluator has created (HIP events on their streams)."""
+        ms, n = 0.0, 0
+        for eng in self._engines.values():
+            if eng is not None:
+                a, b = eng.kernel_time()
+                ms, n = ms + a, n + b
+        return ms, n
+
     def reset_stats(self):
         self.total_games = 0
         self.total_time = 0.0
         self.total_env_steps = 0
+        self.total_decisions = 0
+        for eng in self._engines.values():
+            if eng is not None:
+                eng.reset_stats()

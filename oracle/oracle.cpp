@@ -345,6 +345,43 @@ uint64_t orc_rollout_batch(void* h, int n, const double* w, int max_turns, int n
   return total.load();
 }
 
+// A whole schedule of rollouts on n_threads host threads (the CPU side of the large GPU-vs-CPU comparisons): match k =
+// {p1, p2, seed, deck} plays weights[p1] against weights[p2] on deck pair deck_pairs[deck]; per match: result, decisions,
+// the fault orc_game_fault reports.  Returns the total look-ahead steps.
+struct OrcMatch {
+  int32_t p1, p2;
+  uint32_t seed, deck;
+};
+uint64_t orc_rollout_schedule(const double* weights, const OrcMatch* matches, int n, const uint8_t* deck_pairs, int max_turns, int n_threads,
+                              int8_t* results, int32_t* steps, uint8_t* faults) {
+  std::atomic<int> next(0);
+  std::atomic<uint64_t> total(0);
+  auto worker = [&]() {
+    void* h = orc_create(1);
+    uint64_t mine = 0;
+    for (;;) {
+      int i = next.fetch_add(1);
+      if (i >= n) break;
+      const OrcMatch& m = matches[i];
+      const uint8_t* d = deck_pairs + (size_t)m.deck * 24;
+      int ns = 0, fl = 0;
+      uint64_t nl = 0;
+      int r = -1;
+      if (orc_reset(h, 0, m.seed, d, d + 12, 0, 0) == 0) r = orc_rollout(h, 0, weights + (size_t)m.p1 * 10, weights + (size_t)m.p2 * 10, max_turns, nullptr, nullptr, &ns, &nl, &fl);
+      results[i] = (int8_t)r;
+      steps[i] = ns;
+      faults[i] = (uint8_t)orc_game_fault(h, 0);
+      mine += nl;
+    }
+    total += mine;
+    orc_destroy(h);
+  };
+  std::vector<std::thread> th;
+  for (int t = 0; t < n_threads; t++) th.emplace_back(worker);
+  for (auto& t : th) t.join();
+  return total.load();
+}
+
 // ---- scenario tests (tests/scenario_lib.py): the reference's own unit tests, recorded call by call ---------------
 // Build game gi from a state stream, its numpy stream being RandomState(seed) advanced by stream_pos outputs.
 int orc_scn_build(void* h, int gi, uint32_t seed, uint32_t stream_pos, const int32_t* state) {
@@ -431,6 +468,46 @@ void orc_rng_shuffle(uint32_t seed, int k, int reps, int* out) {
     }
     commit_rng(g, e);
   }
+}
+// monsoon_draw_decks on the CPU: RandomState(seed).choice(pool, 12, replace=False) twice per seed (numpy mtrand.pyx: choice ->
+// permutation -> shuffle with random_interval draws).  Returns the number of seeds that ran past 1 248 outputs (the device's limit).
+int orc_draw_decks(const uint32_t* seeds, int n, const uint8_t* pool, int pool_n, uint8_t* out) {
+  int over = 0;
+  for (int g = 0; g < n; g++) {
+    uint32_t mt[MT_N], words[2 * MT_N];
+    mt_seed(mt, seeds[g]);
+    for (int b = 0; b < 2; b++) {
+      mt_twist(mt);
+      for (int k = 0; k < MT_N; k++) words[b * MT_N + k] = mt_temper(mt[k]);
+    }
+    int pos = 0;
+    bool ov = false;
+    for (int side = 0; side < 2; side++) {
+      uint8_t perm[128];
+      for (int i = 0; i < pool_n; i++) perm[i] = (uint8_t)i;
+      for (int i = pool_n - 1; i >= 1; i--) {
+        uint32_t mask = (uint32_t)i;
+        mask |= mask >> 1;
+        mask |= mask >> 2;
+        mask |= mask >> 4;
+        uint32_t v = 0;
+        do {
+          if (pos >= 2 * MT_N) {
+            ov = true;
+            v = 0;
+            break;
+          }
+          v = words[pos++] & mask;
+        } while (v > (uint32_t)i);
+        uint8_t t = perm[i];
+        perm[i] = perm[v];
+        perm[v] = t;
+      }
+      for (int k = 0; k < 12; k++) out[(size_t)g * 24 + side * 12 + k] = pool[perm[k]];
+    }
+    over += ov;
+  }
+  return over;
 }
 #if defined(MSB_COUNT_FRAMES)
 long long* orc_frame_counts() { return msb_frame_count; }   // study build (scripts/frame_stats.py)

@@ -71,10 +71,31 @@ out = {"tag": tag, "kernel": kd["Name"], "calls": int(kd["Calls"]), "avg_ns": fl
        "pmc": means, "bench_under_trace": bench}
 if "FETCH_SIZE" in means and "WRITE_SIZE" in means:
     out["hbm_bytes_per_launch"] = (2 * means["FETCH_SIZE"]["mean_per_dispatch"] + means["WRITE_SIZE"]["mean_per_dispatch"]) * 1024
+def mean(name):
+    return means[name]["mean_per_dispatch"] if name in means else None
+
+
+# the ceilings that bind this kernel ("VALU utilisation / occupancy ... the meaningful ceilings")
+ceil = {}
+if mean("SQ_THREAD_CYCLES_VALU") and mean("SQ_ACTIVE_INST_VALU"):
+    ceil["lane_utilisation"] = mean("SQ_THREAD_CYCLES_VALU") / mean("SQ_ACTIVE_INST_VALU")   # of 64 lanes per VALU instruction
+if mean("SQ_ACTIVE_INST_VALU") and timed_avg_ns:
+    # a wave64 VALU instruction occupies its SIMD for 4 clocks; 256 CUs x 4 SIMDs at 2.4 GHz
+    ceil["valu_busy"] = mean("SQ_ACTIVE_INST_VALU") * 4 / (1024 * 2.4e9 * timed_avg_ns * 1e-9)
+if mean("SQ_INSTS_SALU") and timed_avg_ns:
+    ceil["salu_busy"] = mean("SQ_INSTS_SALU") / (256 * 2.4e9 * timed_avg_ns * 1e-9)   # one scalar unit per CU
+if "_dispatch" in means and means["_dispatch"]:
+    ceil["waves_per_cu"] = int(means["_dispatch"]["Grid_Size"]) / 64 / 256   # the persistent grid = the resident wavefronts
+    ceil["scratch_bytes_per_lane"] = int(means["_dispatch"]["Scratch_Size"])
+if mean("SQ_WAIT_INST_ANY") and mean("SQ_WAVE_CYCLES"):
+    ceil["wave_time_in_waitcnt"] = mean("SQ_WAIT_INST_ANY") / mean("SQ_WAVE_CYCLES")
+ceil["ceilings_measured_on"] = f"profiles/{tag}_summary.json (rocprofv3 --pmc passes of bench.py {bench_args}), offline like `traffic`"
+out["ceilings"] = ceil
 if "hbm_bytes_per_launch" in out and "--workload" not in bench_args:   # the headline workload only: bench.py quotes this file
     json.dump({"bytes_per_launch": out["hbm_bytes_per_launch"], "source": f"profiles/{tag}_summary.json",
                "formula": "(2*FETCH_SIZE + WRITE_SIZE) * 1024, separate --pmc passes, mean over the hot kernel's dispatches",
-               "measured_on": f"bench.py {bench_args} rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs, {tag}"},
+               "measured_on": f"bench.py {bench_args} rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs, {tag}",
+               "ceilings": ceil},
               open("profiles/traffic.json", "w"), indent=1)
 json.dump(out, open(f"profiles/{tag}_summary.json", "w"), indent=1)
 with open(f"profiles/{tag}_summary.md", "w") as f:

@@ -763,3 +763,166 @@ def test_game_view_and_error_behaviour(engines):
     with pytest.raises(MonsoonError, match="not supported"):
         e.reset(np.array([1], dtype=np.uint32), bad[None])
     e.close()
+
+
+def test_draw_decks_on_device_equals_numpy(engines, gold):
+    """monsoon_draw_decks (configuration C5's per-game decks) against numpy's own RandomState(seed).choice(pool, 12,
+    replace=False): the committed known answers (1 024 seeds, oracle/pyref/gen_deck_draw.py) and 2 000 more seeds drawn by
+    numpy right here; every deck holds 12 distinct observable cards."""
+    from monsoon_amd.cards import draw_random_decks_numpy, observable_pool
+    g = gold("deck_draw_kat.npz")
+    eng = engines(64)
+    assert np.array_equal(g["pool"], observable_pool())
+    assert np.array_equal(eng.draw_decks(g["seeds"], g["pool"]), g["pairs"])
+    seeds = (np.arange(2000, dtype=np.uint64) * np.uint64(2654435761) % np.uint64(2**32)).astype(np.uint32)
+    got = eng.draw_decks(seeds, observable_pool())
+    assert np.array_equal(got, draw_random_decks_numpy(seeds))
+    assert all(len(set(d.tolist())) == 12 for d in got.reshape(-1, 12))
+    small = np.arange(12, dtype=np.uint8)   # a pool of exactly 12 cards: every draw is a permutation of it
+    assert np.array_equal(np.sort(eng.draw_decks(seeds[:50], small).reshape(-1, 12), axis=1), np.tile(small, (100, 1)))
+    from monsoon_amd import MonsoonError
+    with pytest.raises(MonsoonError):
+        eng.draw_decks(seeds[:4], np.arange(11, dtype=np.uint8))   # fewer than 12 cards: refused
+
+
+def test_mixed_schedule_is_tiered_per_game_and_equals_cpu_replay():
+    """A schedule mixing decks with and without ua20 / b005 (4 096 random109 games: 37 % need the extended record): the
+    evaluator plays every game on the smallest record its decks need (fitness.tiered_rollout) and every row -- counts,
+    results, decision counts, fault codes -- equals the CPU replay doing the same; the same schedule forced onto the
+    extended record gives the same rows wherever no record limit was hit (the record layout is not observable)."""
+    from oracle_rollout import oracle_draw_decks, oracle_rollout_fn_mt
+    from monsoon_amd.cards import needs_extended_each, observable_pool
+    from monsoon_amd.config import EvolutionaryConfig
+    from monsoon_amd.fitness import MATCH_DTYPE, FitnessEvaluator
+    n = 4096
+    rs = np.random.RandomState(77)
+    m = np.zeros(n, dtype=MATCH_DTYPE)
+    m["seed"] = rs.randint(0, 2**31, n)
+    m["p1"], m["p2"] = rs.randint(0, 6, n), rs.randint(0, 6, n)
+    m["deck"] = np.arange(n)
+    weights = rs.uniform(0, 1, (6, 10))
+    fe = FitnessEvaluator(EvolutionaryConfig(max_concurrent_games=4096, max_turns=200))
+    pairs = fe._engine(0).draw_decks(m["seed"] ^ np.uint32(0x9E3779B9), observable_pool())
+    assert np.array_equal(pairs, oracle_draw_decks(m["seed"] ^ np.uint32(0x9E3779B9), observable_pool()))
+    ext = needs_extended_each(pairs)
+    assert 0.25 < ext.mean() < 0.5
+    counts = fe._hip_rollout(weights, m, pairs, 200)
+    results, steps, faults = fe.last_rollout
+    assert fe.tier_games == [int((~ext).sum()), int(ext.sum())]
+    oc, ores, osteps, of = oracle_rollout_fn_mt(weights, m, pairs, 200, want_faults=True)
+    assert np.array_equal(counts, oc) and np.array_equal(results, ores) and np.array_equal(steps, osteps) and np.array_equal(faults, of)
+    from monsoon_amd.engine import BatchEngine
+    e1 = BatchEngine(n, extended=True)   # everything on the extended record
+    _, r1, s1 = e1.rollout(weights, m, pairs, 200, want_results=True)
+    ok = (e1.rollout_faults(n) < 16) & (faults < 16)
+    assert ok.mean() > 0.99 and np.array_equal(r1[ok], results[ok]) and np.array_equal(s1[ok], steps[ok])
+    e1.close()
+
+
+def test_two_rollouts_with_a_small_tail_on_one_handle(engines):
+    """A schedule of max_games + a tail smaller than the resident grid, twice on one handle: persistent, non-persistent,
+    persistent, non-persistent launches of the hot kernel in turn.  The persistent form's game counters alternate
+    between two sets, one of which a launch clears for the next: a non-persistent launch in between must not advance
+    that alternation (round 2 did: the next persistent launch then played only the first game of every range and
+    reported the rest as draws).  Every row equals the CPU replay."""
+    from oracle_rollout import oracle_rollout_tier
+    cap = 16384
+    n = cap + 300
+    deck = deck_indices("S12")
+    pairs = np.stack([deck, deck])[None]
+    eng = engines(cap)
+    rs = np.random.RandomState(3)
+    weights = rs.uniform(0, 1, (4, 10))
+    for rep in range(2):
+        m = np.zeros(n, dtype=[("p1", "<i4"), ("p2", "<i4"), ("seed", "<u4"), ("deck", "<u4")])
+        m["seed"] = 7000 + rep * n + np.arange(n)
+        m["p1"], m["p2"] = rs.randint(0, 4, n), rs.randint(0, 4, n)
+        counts, results, steps = eng.rollout(weights, m, pairs, 200, want_results=True)
+        oc, ores, osteps, of = oracle_rollout_tier(weights, m, pairs, 200, 0, threads=16)
+        assert np.array_equal(results, ores) and np.array_equal(steps, osteps) and np.array_equal(counts, oc), rep
+        assert (steps > 0).all()
+
+
+def test_config_c3_full_size_ten_generations(tmp_path):
+    """BASELINE configs[2] (C3) at its full size: mu = lambda = 128, 64 games per individual, N12M, ten generations (8 192 +
+    9 x 16 384 = 155 648 games, ~0.7 G env-steps) through EvolutionEngine -> FitnessEvaluator -> monsoon_rollout; fitness
+    lists, selected population and best individual equal the same GA run on the 16-thread CPU replay."""
+    from oracle_rollout import oracle_rollout_fn_mt
+    from monsoon_amd.config import EvolutionaryConfig
+    from monsoon_amd.evolution import EvolutionEngine
+    runs = []
+    for name, fn in (("hip", None), ("cpu", oracle_rollout_fn_mt)):
+        cfg = EvolutionaryConfig(mu=128, lambda_=128, generations=10, min_generations=50, schedule="ring", games_per_individual=64, deck="N12M",
+                                 max_turns=200, seed=42, results_dir=str(tmp_path / name), save_logs=False, checkpoint_interval=1000,
+                                 max_concurrent_games=16384)
+        eng = EvolutionEngine(cfg, rollout_fn=fn)
+        eng.initialize()
+        res = eng.run()
+        runs.append((list(eng.population.fitness_scores), np.stack([i.get_weights() for i in eng.population.individuals]), res))
+        if fn is None:
+            assert eng.fitness_evaluator.get_stats()["total_games"] == 128 * 64 + 9 * 256 * 64
+    (f_hip, w_hip, r_hip), (f_cpu, w_cpu, r_cpu) = runs
+    assert f_hip == f_cpu and np.array_equal(w_hip.view(np.uint64), w_cpu.view(np.uint64))
+    assert r_hip["best_fitness"] == r_cpu["best_fitness"] and r_hip["generations"] == 10
+
+
+def test_config_c4_full_size_on_one_gpu():
+    """BASELINE configs[3] (C4) at its full size on one GPU: population 1 024 on the Swarm deck S12, ring schedule, 64 games per
+    individual = 65 536 games; per-individual fitness, every result and every decision count equal the CPU replay."""
+    from oracle_rollout import oracle_rollout_fn_mt
+    from monsoon_amd.config import EvolutionaryConfig
+    from monsoon_amd.fitness import FitnessEvaluator
+    from monsoon_amd.weights import WeightVector
+    np.random.seed(5)
+    pop = [WeightVector(10) for _ in range(1024)]
+    cfg = EvolutionaryConfig(mu=1024, lambda_=1024, schedule="ring", games_per_individual=64, deck="S12", max_turns=200, max_concurrent_games=65536)
+    hip, cpu = FitnessEvaluator(cfg), FitnessEvaluator(cfg, rollout_fn=lambda *a, **k: oracle_rollout_fn_mt(*a, want_faults=True, **k)[0])
+    f_hip = hip.evaluate_population(pop, generation=7)
+    assert f_hip == cpu.evaluate_population(pop, generation=7) and hip.get_stats()["total_games"] == 65536
+    assert hip.capacity_faults == 0 and len(set(f_hip)) > 30   # fitness values are multiples of 1/128
+
+
+def test_config_c5_one_generation_full_size():
+    """BASELINE configs[4] (C5), one whole generation on one GPU: population 4 096, 128 games per individual = 524 288 games,
+    every game its own two decks drawn on the device from the 109 observable cards (monsoon_draw_decks), played on the
+    record its decks need, overflowing games replayed on the next larger one -- through FitnessEvaluator.evaluate_population.
+    Fitness of all 4 096 individuals, every result, decision count and fault code equal the CPU replay of the same schedule
+    (decks by the CPU restatement of the draw, itself pinned to numpy's); what still ends on a record limit is reported."""
+    import time
+    from oracle_rollout import oracle_draw_decks, oracle_rollout_fn_mt
+    from monsoon_amd.cards import RANDOM_DECK
+    from monsoon_amd.config import EvolutionaryConfig
+    from monsoon_amd.fitness import FitnessEvaluator
+    from monsoon_amd.weights import WeightVector
+    np.random.seed(11)
+    pop = [WeightVector(10) for _ in range(4096)]
+    cfg = EvolutionaryConfig(mu=4096, lambda_=4096, schedule="ring", games_per_individual=128, deck=RANDOM_DECK, max_turns=200,
+                             max_concurrent_games=65536)
+    hip = FitnessEvaluator(cfg)
+    hip.use_hall_of_fame = False
+    hip.evaluate_population(pop[:64], generation=0)   # creates the engines of both tiers
+    hip.reset_stats()
+    hip.tier_games, hip.capacity_replays, hip.capacity_faults = [0, 0], 0, 0
+    t0 = time.time()
+    f_hip = hip.evaluate_population(pop, generation=3)
+    t_hip = time.time() - t0
+    results, steps, faults = hip.last_rollout
+    box = {}
+
+    def cpu_rollout(weights, matches, deck_pairs, max_turns):
+        box["rows"] = oracle_rollout_fn_mt(weights, matches, deck_pairs, max_turns, want_faults=True)
+        return box["rows"][0]
+    cpu = FitnessEvaluator(cfg, rollout_fn=cpu_rollout, deck_draw_fn=oracle_draw_decks)
+    cpu.use_hall_of_fame = False
+    t0 = time.time()
+    f_cpu = cpu.evaluate_population(pop, generation=3)
+    t_cpu = time.time() - t0
+    _, ores, osteps, of = box["rows"]
+    assert f_hip == f_cpu
+    assert np.array_equal(results, ores) and np.array_equal(steps, osteps) and np.array_equal(faults, of)
+    st = hip.get_stats()
+    assert st["total_games"] == 524288 and sum(hip.tier_games) == 524288 and hip.tier_games[1] > 150000
+    left = int((faults >= 16).sum())
+    print(f"C5 generation: {t_hip:.2f} s on the GPU end to end ({st['env_steps'] / 1e6:.0f} M env-steps), {t_cpu:.1f} s CPU replay; "
+          f"tiers {hip.tier_games}, {hip.capacity_replays} replayed, {left} left on a record limit")
+    assert left <= 524288 // 2000   # 0.05 %: nested copies beyond 254 entity objects, recursion beyond the guard (DESIGN.md)

@@ -180,3 +180,35 @@ def test_every_card_with_an_ability_has_a_case():
     assert sorted(entity) == sorted(c["id"] for c in meta if c["kind"] != 2 and c["has_ability"])
     assert sorted(spells) == sorted(c["id"] for c in meta if c["kind"] == 2)
     assert len(set(entity)) == len(entity) and len(set(spells)) == len(spells)
+
+
+def test_random109_decks_and_per_game_tiers_on_the_cpu_stand_in():
+    """Configuration C5's deck rule through the evaluator (CPU stand-in for the rollout): per-game decks from the game's own
+    pre-stream -- the CPU restatement of the draw gives the same schedule as numpy itself --, every game on the smallest
+    record its decks need, and the tiered rows equal the rows of the same schedule played on the extended record alone
+    wherever no record limit was met."""
+    from oracle_rollout import oracle_draw_decks, oracle_rollout_fn, oracle_rollout_tier
+    from monsoon_amd.cards import RANDOM_DECK, needs_extended_each
+    from monsoon_amd.config import EvolutionaryConfig
+    from monsoon_amd.fitness import FitnessEvaluator
+    from monsoon_amd.weights import WeightVector
+    np.random.seed(3)
+    pop = [WeightVector(10) for _ in range(6)]
+    cfg = EvolutionaryConfig(mu=6, lambda_=6, schedule="ring", games_per_individual=5, deck=RANDOM_DECK, max_turns=40)
+    seen = []
+
+    def spy(weights, matches, deck_pairs, max_turns):
+        seen.append((np.array(matches), np.array(deck_pairs)))
+        return oracle_rollout_fn(weights, matches, deck_pairs, max_turns)
+    f_numpy = FitnessEvaluator(cfg, rollout_fn=spy).evaluate_population(pop, 2)
+    f_orc = FitnessEvaluator(cfg, rollout_fn=spy, deck_draw_fn=oracle_draw_decks).evaluate_population(pop, 2)
+    assert f_numpy == f_orc and np.array_equal(seen[0][1], seen[1][1]) and seen[0][1].shape == (30, 2, 12)
+    m, pairs = seen[0]
+    assert np.array_equal(m["deck"], np.arange(30)) and all(len(set(d.tolist())) == 12 for d in pairs.reshape(-1, 12))
+    ext = needs_extended_each(pairs)
+    assert ext.any() and not ext.all()
+    w = np.stack([p.weights for p in pop])
+    _, r_t, s_t, f_t = oracle_rollout_fn(w, m, pairs, 40, want_faults=True)
+    _, r_e, s_e, f_e = oracle_rollout_tier(w, m, pairs, 40, 1)
+    ok = (f_t < 16) & (f_e < 16)
+    assert ok.all() and np.array_equal(r_t, r_e) and np.array_equal(s_t, s_e) and np.array_equal(f_t, f_e)

@@ -284,3 +284,14 @@ def test_replay_tier_for_games_the_extended_record_cannot_hold():
     assert np.array_equal(r1[~over], r2[~over]) and np.array_equal(s1[~over], s2[~over])
     assert (ft >= 16).sum() < over.sum() and (ft >= 16).sum() <= 2       # 2063 does not fit 254 slots either
     assert ct[0, 2] == len(idx) and ct[0, 0] == (rt == 0).sum() and ct[0, 1] == (rt == -1).sum()
+
+
+def test_deck_draw_restatement_vs_numpy(gold):
+    """orc_draw_decks (the CPU restatement of monsoon_draw_decks) against numpy's own RandomState(seed).choice(pool, 12,
+    replace=False): the committed known answers and 300 seeds drawn by numpy right here."""
+    from oracle_rollout import oracle_draw_decks
+    from monsoon_amd.cards import draw_random_decks_numpy, observable_pool
+    g = gold("deck_draw_kat.npz")
+    assert np.array_equal(oracle_draw_decks(g["seeds"], g["pool"]), g["pairs"])
+    seeds = np.arange(300, dtype=np.uint32) * np.uint32(40503) + np.uint32(17)
+    assert np.array_equal(oracle_draw_decks(seeds, observable_pool()), draw_random_decks_numpy(seeds))
