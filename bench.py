@@ -280,7 +280,7 @@ def bench_c2(args, rank, world, local_rank, fake, barrier, all_sum, all_max):
     traffic, traffic_on, ceilings = recorded_traffic()
     # what the kernel has to move at the least: every game's record and meta row in and out once per launch (the RNG
     # words it draws and the block refills come on top; SURVEY's per-step figure assumes a record read per look-ahead)
-    physical = float(n) * 2 * (832 + 32)
+    physical = float(n) * 2 * (752 + 32)
     line = {
         "metric": METRIC,
         "value": tot_look / max_dt,

@@ -13,7 +13,7 @@
 //     ds_read_b128.  Scores are reduced with shuffles over the U candidate lanes (first maximum in ascending action
 //     order = np.argmax over the sorted legal list) and the winner's column becomes the game's record.  Nothing
 //     is re-executed: the committed successor IS one of the look-ahead results (when the legal set needs several
-//     passes of U lanes, the best successor so far is parked in a spare LDS record), and its features are the next
+//     passes of U lanes, the best successor so far is parked in the game's HBM record), and its features are the next
 //     decision's "before" features.
 //   * The game's MT19937 stream lives in HBM as two blocks of tempered outputs (current + next) plus the raw
 //     state; candidate steps read it through a private cursor, the committed cursor travels with the record and
@@ -76,7 +76,7 @@ struct DevBuffers {
 #if defined(MSB_SKW)
 constexpr int SKW = MSB_SKW;
 #else
-constexpr int SKW = 24;
+constexpr int SKW = 21;
 #endif
 static_assert(SKW >= SK_NEED + 9 && SKW * 4 >= 80, "room for the largest frame + the eviction mark + what a handler pushes; the candidates' features overlay their stacks");
 constexpr int OVF_WORDS = SK_CAP;   // per stepping lane
@@ -197,7 +197,7 @@ constexpr int LDS_ORIGIN = LDS_RECORDS;
 // Hot kernel: a wavefront takes a game, keeps its record in LDS and plays up to `rounds` decisions of it (look-ahead +
 // score + argmax + commit each) before it writes the record back and takes the next game.
 // Dynamic LDS map (bytes): weight table | [PRIV, +SG*U*16) candidate records, lane-interleaved in 16-byte granules |
-// the game's current record | the parked best successor | 10 weights + 10 "before" + 10 "best after" features |
+// the game's current record | 10 weights + 10 "before" + 10 "best after" features |
 // the candidates' "after" features | the candidates' work stacks (SKW words each, interleaved word by word)
 // ------------------------------------------------------------------------------------------------
 __device__ MSB_INL int nth_set_bit(const uint64_t mask[3], int k) {
@@ -218,8 +218,7 @@ struct DecideLds {
   static constexpr int PRIV = LDS_ORIGIN;
   static constexpr int PRIV_BYTES = SG * U * 16 > MT_N * 4 ? SG * U * 16 : ((MT_N * 4 + 15) & ~15);   // doubles as the twist buffer
   static constexpr int PAR = PRIV + PRIV_BYTES;      // the game's current record
-  static constexpr int BEST = PAR + SG * 16;         // best successor so far of a decision that needs several passes
-  static constexpr int WF = BEST + SG * 16;          // 10 weights + 10 "before" features + 10 features of the best successor (f64)
+  static constexpr int WF = PAR + SG * 16;           // 10 weights + 10 "before" features + 10 features of the best successor (f64)
   static constexpr int SKB = WF + 240;               // work stacks of the U candidate lanes ...
   static constexpr int CF = SKB;                     // ... and, once a pass has stepped (stacks empty), their ten "after" features each (f64)
   static constexpr int TOTAL = SKB + U * SKW * 4;
@@ -249,7 +248,6 @@ __device__ MSB_INL void play_game(const DevBuffers& b, const int g, const int la
   PROF_DECL();
   MSB_AS_LDS u32x4* par = (MSB_AS_LDS u32x4*)(uintptr_t)L::PAR;
   MSB_AS_LDS u32x4* priv = (MSB_AS_LDS u32x4*)(uintptr_t)L::PRIV;
-  MSB_AS_LDS u32x4* bestcol = (MSB_AS_LDS u32x4*)(uintptr_t)L::BEST;
   MSB_AS_LDS double* wf = (MSB_AS_LDS double*)(uintptr_t)L::WF;
   MSB_AS_LDS double* cf = (MSB_AS_LDS double*)(uintptr_t)(L::CF + (lane < U ? lane : 0) * 80);   // this candidate lane's features
   u32x4* grec = (u32x4*)(b.state + (size_t)g * SW);
@@ -300,7 +298,7 @@ __device__ MSB_INL void play_game(const DevBuffers& b, const int g, const int la
     PROF_MARK(2);   // before-features
 
     // Running best over the passes (uniform across the wave).  When the legal set needs more than
-    // one pass, the best successor so far is parked in a spare LDS record so that nothing is replayed.
+    // one pass, the best successor so far is parked in the game's record in HBM so that nothing is replayed.
     // (Parking it in its own column and running later passes on the other U - 1 columns saves that record and the
     // copy, but measured 6 % slower: more passes.)
     constexpr int NONE_A = 1 << 20;
@@ -387,9 +385,10 @@ __device__ MSB_INL void play_game(const DevBuffers& b, const int g, const int la
         if (feat_ok && lane < 10)   // the winner keeps its features: the next decision's "before" side
           wf[20 + lane] = ((MSB_AS_LDS const double*)(uintptr_t)L::CF)[wl * 10 + lane];
         if (multi) {
+          // park it in the game's record in HBM: that slot is free while the live record sits in LDS (one coalesced
+          // 16-byte-per-lane store; a spare LDS record here would cost every wavefront a record's worth of LDS = two wavefronts per CU)
           __syncthreads();
-          for (int c = lane; c < SG; c += 64) bestcol[c] = priv[c * U + wl];
-          __syncthreads();
+          for (int c = lane; c < SG; c += 64) grec[c] = priv[c * U + wl];
         }
       }
       PROF_MARK(6);   // argmax + park
@@ -397,7 +396,12 @@ __device__ MSB_INL void play_game(const DevBuffers& b, const int g, const int la
     __syncthreads();
     // commit: adapter = adapter.apply_action(best).  The successor carries its own stream cursor (H_RNGPOS).
     if (multi) {
-      for (int c = lane; c < SG; c += 64) par[c] = bestcol[c];
+      // read back what this wavefront parked: agent-scope loads, so that the per-CU vector cache cannot answer with an
+      // older line of the record
+      for (int c = lane; c < 2 * SG; c += 64) {
+        unsigned long long v = __hip_atomic_load((unsigned long long*)grec + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        ((MSB_AS_LDS unsigned long long*)par)[c] = v;
+      }
     } else {
       for (int c = lane; c < SG; c += 64) par[c] = priv[c * U + wl];
     }

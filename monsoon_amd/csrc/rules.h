@@ -668,7 +668,7 @@ struct Engine {
   MSB_HD MSB_INL void begin_step() {
     MSB_SCOPE(PS_BEGIN_STEP);
     // one shift per tile, no compare: an empty tile (0xFF) sets the top bit, which is not an entity slot
-    static_assert((SLOT_NONE & 31) >= 28, "the empty marker must map outside the slot bits");
+    static_assert(NUM_ENT > 32 || (SLOT_NONE & 31) >= NUM_ENT, "the empty marker must map outside the slot bits");
     Bits used = Bits::none();
     for (int y = 0; y < 5; y++) {
       uint32_t row = board_row(y);
@@ -2344,7 +2344,8 @@ struct Engine {
   // Stormbound.step, games/stormbound.py:318-373 (without the observation; see observe.inc).
   // The caller guarantees `action` is in legal_actions().  Returns reward | done << 1 as the reference
   // computes them.  A play leaves frames for run(); so does passing the turn on, which has nothing before it.
-  MSB_HD MSB_INL int step(int action) {
+  MSB_HD MSB_INL int step(int action) { return step_impl(action); }
+  MSB_HD MSB_A_STEP int step_impl(int action) {
     MSB_SCOPE(PS_STEP);
     Wk k{0, 0, 0, 0};
     begin_step();

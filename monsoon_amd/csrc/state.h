@@ -26,7 +26,12 @@ constexpr int NUM_ENT = 254;  // the LARGE record: every slot id a byte can name
 #elif defined(MSB_EXT) && MSB_EXT
 constexpr int NUM_ENT = 128;  // 20 tiles + transient + b005's remembered copies + the entities of frozen world snapshots
 #else
-constexpr int NUM_ENT = 28;    // 20 tiles + 8 transient (dead / displaced / spawned this step)
+// 20 tiles + 4 transient (dead / displaced / spawned this step).  Round 3: 24 instead of 28 -- a 752-byte record, which
+// together with the best successor parked in HBM lets 20 instead of 17 wavefronts share a CU's LDS.  No step of 68 000
+// heuristic games on five deck families (N12M, S12, N12V, Ironclad vs Swarm, 20 000 random 107-card deck pairs) needs a
+// 25th slot (22 slots: one game does, 21: 30 games; scripts/capacity_standard.py); a game that ever does reports
+// FAULT_CAPACITY and the rollout path plays it again on the extended record (128 slots), like any other record limit.
+constexpr int NUM_ENT = 24;
 #endif
 constexpr int HAND_CAP = 5;    // 4, transiently 5 (b305 returns itself to hand)
 constexpr int DECK_SIZE = 12;  // cards per deck at construction (games/stormbound.py:295-302)

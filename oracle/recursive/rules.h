@@ -656,7 +656,7 @@ struct Engine {
   MSB_HD MSB_INL void begin_step() {
     MSB_SCOPE(PS_BEGIN_STEP);
     // one shift per tile, no compare: an empty tile (0xFF) sets the top bit, which is not an entity slot
-    static_assert((SLOT_NONE & 31) >= 28, "the empty marker must map outside the slot bits");
+    static_assert(NUM_ENT > 32 || (SLOT_NONE & 31) >= NUM_ENT, "the empty marker must map outside the slot bits");
     Bits used = Bits::none();
     for (int y = 0; y < 5; y++) {
       uint32_t row = board_row(y);

@@ -1,20 +1,25 @@
 #!/bin/bash
-# One validation pass on the GPU box (gpurun -- bash scripts/gpu_validate.sh): parity tests, the C5 slice against the
-# CPU replay, rollout timings, the default bench line.  Everything lands under gpurun_out/validate_*.
+# One validation pass on the GPU box (gpurun -- bash scripts/gpu_validate.sh [tag]): the default bench line (C2, with the CPU
+# baseline), the C3 / C4 / C5 generation lines, whole-rollout timings, the C3 GA loop.  Everything lands under gpurun_out/validate_<tag>_*.
+TAG=${1:-r03}
 mkdir -p gpurun_out
-python -m pytest tests -m gpu -x -q > gpurun_out/validate_tests.log 2>&1
-rc=$?
-echo "gpu tests rc=$rc"; tail -3 gpurun_out/validate_tests.log
-[ $rc -ne 0 ] && exit $rc
-python scripts/c5_parity.py 32768 > gpurun_out/validate_c5.log 2>&1; echo "c5 rc=$?"; tail -1 gpurun_out/validate_c5.log
-for d in "16384 N12M" "65536 N12M" "16384 S12" "16384 random"; do
-  set -- $d
-  python scripts/rollout_timing.py $1 $2 > gpurun_out/validate_rollout_$1_$2.log 2>&1; tail -2 gpurun_out/validate_rollout_$1_$2.log
+O=gpurun_out/validate_${TAG}
+timeout -k 10 300 python bench.py > ${O}_bench.json 2> ${O}_bench.err; echo "bench rc=$?"
+for w in c3 c4 c5; do
+  timeout -k 10 300 python bench.py --workload $w > ${O}_bench_$w.json 2> ${O}_bench_$w.err; echo "bench $w rc=$?"
 done
-python bench.py > gpurun_out/validate_bench.json 2> gpurun_out/validate_bench.err; echo "bench rc=$?"
-python - <<'PY'
+for d in "16384 N12M" "65536 N12M" "16384 S12" "65536 S12" "16384 random"; do
+  set -- $d
+  timeout -k 10 300 python scripts/rollout_timing.py $1 $2 > ${O}_rollout_$1_$2.log 2>&1; tail -2 ${O}_rollout_$1_$2.log
+done
+timeout -k 10 300 python scripts/run_c3.py > ${O}_run_c3.json 2> ${O}_run_c3.err; echo "run_c3 rc=$?"
+python - <<PY
 import json
-d = json.loads(open("gpurun_out/validate_bench.json").read().strip().splitlines()[-1])
+d = json.loads(open("${O}_bench.json").read().strip().splitlines()[-1])
 print("bench: %.1f M env-steps/s, %.3f ms/step, k_play %.3f ms, roofline frac %.3f, cpu baseline %.1f M on %d cores" % (
     d["value"] / 1e6, d["ms_per_step"], d["roofline"]["avg_launch_ms"], d["roofline"]["frac"], d["cpu_baseline"]["value"] / 1e6, d["cpu_baseline"]["cores"]))
+for w in ("c3", "c4", "c5"):
+    d = json.loads(open("${O}_bench_%s.json" % w).read().strip().splitlines()[-1])
+    print("bench %s: %.1f M env-steps/s end to end, %.1f ms per generation (k_play %.1f ms, host + other %.1f ms), tiers %s" % (
+        w, d["value"] / 1e6, d["ms_per_step"], d["roofline"]["kernel_ms_per_step"], d["roofline"]["host_and_other_ms_per_step"], d["record_tiers"]))
 PY

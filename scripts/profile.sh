@@ -1,5 +1,5 @@
 #!/bin/bash
-# Round-2 profile recipe (run on the GPU box via gpurun from the repo root): $1 = tag, $2.. = bench.py arguments.
+# Profile recipe (run on the GPU box via gpurun from the repo root): $1 = tag, $2.. = bench.py arguments.
 # Kernel trace + stats and the PMC counters in SEPARATE passes (MI355X_MICROARCH.md: FETCH_SIZE takes 3 TCC slots,
 # WRITE_SIZE 2; gpurun refuses --pmc combined with trace domains other than kernel-trace).
 set -e
