@@ -79,7 +79,17 @@ def fitness_from_counts(counts, games_per_individual):
     return [float((counts[i, 0] + 0.5 * counts[i, 1]) / games_per_individual) for i in range(len(counts))]
 
 
-CAPACITY_CODE = 16   # fault codes >= this are limits of a build's record (csrc/msb_base.h), not reference behaviour
+CAPACITY_CODE = 16   # fault codes >= this are limits of a build's record (csrc/msb_base.h), not reference behaviour ...
+DEPTH_CODE = 18      # ... except the recursion guard: 40 nested abilities / moves.  Where that trips the reference's own
+#                      recursion ends in RecursionError (raising the guard to 200 changes no game; the reference's trace of such
+#                      a game is part of tests/golden/trace_heuristic_c5_big.npz), and the guard is the same on every record: such
+#                      a game is a draw like any other exception, it is not replayed and not counted as a record limit
+
+
+def record_limited(faults):
+    """bool[n]: the games a LARGER record could play further (capacity codes other than the recursion guard)."""
+    faults = np.asarray(faults)
+    return (faults >= CAPACITY_CODE) & (faults != DEPTH_CODE)
 
 
 def replace_capacity_faulted(counts, results, steps, faults, matches, replay):
@@ -137,7 +147,7 @@ def tiered_rollout(play, n_rows, matches, deck_pairs):
         results[idx], steps[idx], faults[idx] = r, s_, f
     replays = 0
     for t in (1, 2):   # standard -> extended -> large
-        bad = np.nonzero((faults >= CAPACITY_CODE) & (tier < t))[0]
+        bad = np.nonzero(record_limited(faults) & (tier < t))[0]
         if not len(bad):
             continue
         replays += len(bad)
@@ -153,7 +163,7 @@ def tiered_rollout(play, n_rows, matches, deck_pairs):
 
 
 class FitnessEvaluator:
-    def __init__(self, config, deck_config=None, rollout_fn=None, device=None, deck_draw_fn=None):
+    def __init__(self, config, deck_config=None, rollout_fn=None, device=None, deck_draw_fn=None, strict=False):
         self.config = config
         self.deck_config = deck_config      # monsoon_amd.decks.DeckEvolutionConfig (utils.py:121-242) or None = config.deck both sides
         self.total_games = 0
@@ -168,6 +178,8 @@ class FitnessEvaluator:
         self._device = device
         self._engines = {}
         self.eval_times = []            # wall seconds of every evaluate_population call (the first one creates the engine)
+        self.strict = strict            # True: a game left on a record limit raises instead of being scored as a draw
+        self.depth_faults = 0           # games ended by the recursion guard (the reference's RecursionError), draws
         self.capacity_replays = 0       # games replayed on the large record
         self.capacity_faults = 0        # games not even the large record could hold (their fault code ends them as draws)
         self.tier_games = [0, 0]        # games first played on the standard / the extended record
@@ -196,7 +208,16 @@ class FitnessEvaluator:
 
         counts, results, steps, faults, replays, sizes = tiered_rollout(play, len(weights), matches, deck_pairs)
         self.capacity_replays += replays
-        self.capacity_faults += int((faults >= CAPACITY_CODE).sum())
+        left = int(record_limited(faults).sum())
+        self.capacity_faults += left
+        self.depth_faults += int((faults == DEPTH_CODE).sum())
+        if left:
+            msg = (f"{left} of {len(matches)} games still end on a limit of the largest record (fault codes "
+                   f"{sorted(set(faults[record_limited(faults)].tolist()))}): scored as draws, parity with the reference unpinned for them")
+            if self.strict:
+                raise RuntimeError(msg)
+            import warnings
+            warnings.warn(msg, RuntimeWarning, stacklevel=2)
         self.tier_games = [a + b for a, b in zip(self.tier_games, sizes)]
         self.last_rollout = (results, steps, faults)
         return counts
@@ -309,6 +330,7 @@ class FitnessEvaluator:
                 "avg_time_per_game": self.total_time / max(self.total_games, 1),
                 "games_per_second": self.total_games / max(self.total_time, 1e-6),
                 "env_steps": self.total_env_steps, "capacity_replays": self.capacity_replays, "capacity_faults": self.capacity_faults,
+                "depth_faults": self.depth_faults,
                 "env_steps_per_second": self.total_env_steps / max(self.total_time, 1e-6)}
 
     def kernel_time(self):

@@ -558,7 +558,9 @@ def test_fitness_rollout_replays_overflowing_games_on_the_large_record():
     assert np.array_equal(counts, ocounts) and counts[:, 2].sum() == len(idx)
     assert np.array_equal(results, ores) and np.array_equal(steps, osteps) and np.array_equal(faults, ofaults)
     st = fe.get_stats()
-    assert st["capacity_replays"] >= len(C5_OVERFLOWING) - 1 and st["capacity_faults"] == int((ofaults >= 16).sum()) <= 4
+    from monsoon_amd.fitness import record_limited
+    assert st["capacity_replays"] >= len(C5_OVERFLOWING) - 1 and st["capacity_faults"] == int(record_limited(ofaults).sum()) <= 4
+    assert st["depth_faults"] == int((ofaults == 18).sum())   # the recursion guard = the reference's RecursionError: never replayed
 
 
 def test_handles_of_several_builds_alive_at_once():
@@ -922,7 +924,9 @@ def test_config_c5_one_generation_full_size():
     assert np.array_equal(results, ores) and np.array_equal(steps, osteps) and np.array_equal(faults, of)
     st = hip.get_stats()
     assert st["total_games"] == 524288 and sum(hip.tier_games) == 524288 and hip.tier_games[1] > 150000
-    left = int((faults >= 16).sum())
+    from monsoon_amd.fitness import record_limited
+    left, deep = int(record_limited(faults).sum()), int((faults == 18).sum())
     print(f"C5 generation: {t_hip:.2f} s on the GPU end to end ({st['env_steps'] / 1e6:.0f} M env-steps), {t_cpu:.1f} s CPU replay; "
-          f"tiers {hip.tier_games}, {hip.capacity_replays} replayed, {left} left on a record limit")
-    assert left <= 524288 // 2000   # 0.05 %: nested copies beyond 254 entity objects, recursion beyond the guard
+          f"tiers {hip.tier_games}, {hip.capacity_replays} replayed, {left} left on a record limit, {deep} ended by the recursion guard")
+    assert left == hip.capacity_faults and deep == hip.depth_faults
+    assert left <= 524288 // 2000   # 0.05 %: nested copies beyond 254 entity objects

@@ -212,3 +212,47 @@ def test_random109_decks_and_per_game_tiers_on_the_cpu_stand_in():
     _, r_e, s_e, f_e = oracle_rollout_tier(w, m, pairs, 40, 1)
     ok = (f_t < 16) & (f_e < 16)
     assert ok.all() and np.array_equal(r_t, r_e) and np.array_equal(s_t, s_e) and np.array_equal(f_t, f_e)
+
+
+def test_recursion_guard_is_not_a_record_limit_and_strict_mode_raises():
+    """fitness.tiered_rollout: a game ended by the recursion guard (code 18: the reference's RecursionError, the same on every
+    record) is never replayed; a game left on a record limit after the largest tier is reported -- a warning, or an error
+    with strict=True."""
+    import warnings
+    from monsoon_amd.config import EvolutionaryConfig
+    from monsoon_amd.fitness import MATCH_DTYPE, FitnessEvaluator, record_limited, tiered_rollout
+    assert record_limited(np.array([0, 1, 16, 18, 22], dtype=np.uint8)).tolist() == [False, False, True, False, True]
+    m = np.zeros(4, dtype=MATCH_DTYPE)
+    m["seed"] = np.arange(4)
+    pairs = np.zeros((1, 2, 12), dtype=np.uint8)
+    calls = []
+
+    def play(tier, sub, sub_pairs):
+        calls.append((tier, sub["seed"].tolist()))
+        f = np.array([{0: 18, 1: 16, 2: 0, 3: 23}[int(s)] if tier < 2 else (16 if s == 3 else 0) for s in sub["seed"]], dtype=np.uint8)
+        r = np.where(f != 0, -1, 0).astype(np.int8)
+        c = np.zeros((1, 3), dtype=np.int64)
+        c[0] = [(r == 0).sum(), (r == -1).sum(), len(sub)]
+        return c, r, np.full(len(sub), 7, dtype=np.int32), f
+    counts, results, steps, faults, replays, sizes = tiered_rollout(play, 1, m, pairs)
+    assert calls == [(0, [0, 1, 2, 3]), (1, [1, 3]), (2, [1, 3])] and replays == 4 and sizes == [4, 0]
+    assert faults.tolist() == [18, 0, 0, 16] and counts[0].tolist() == [2, 2, 4]
+    cfg = EvolutionaryConfig(max_turns=5)
+    for strict in (False, True):
+        fe = FitnessEvaluator(cfg, strict=strict)
+        fe._engine = lambda tier: None
+        import monsoon_amd.fitness as F
+        orig = F.tiered_rollout
+        F.tiered_rollout = lambda play_, n, mm, pp: tiered_rollout(play, n, mm, pp)
+        try:
+            if strict:
+                import pytest
+                with pytest.raises(RuntimeError, match="still end on a limit"):
+                    fe._hip_rollout(np.zeros((1, 10)), m, pairs, 5)
+            else:
+                with warnings.catch_warnings(record=True) as w:
+                    warnings.simplefilter("always")
+                    fe._hip_rollout(np.zeros((1, 10)), m, pairs, 5)
+                assert fe.capacity_faults == 1 and fe.depth_faults == 1 and any("still end on a limit" in str(x.message) for x in w)
+        finally:
+            F.tiered_rollout = orig
