@@ -173,6 +173,33 @@ int monsoon_rollout_faults(monsoon_t* h, uint8_t* out, int32_t n_matches);
  * (150 us per game in numpy, 79 s for one C5 generation). */
 int monsoon_draw_decks(monsoon_t* h, const uint32_t* seeds, int32_t n, const uint8_t* pool, int32_t pool_n, uint8_t* out_pairs);
 
+/* GA operators on the device.  The host GA (monsoon_amd/population.py, as the reference's
+ * evo/population.py) stays the default and the bit-exact path; these are the same operators over the same numpy stream
+ * for a driver that wants the population to stay next to the rollouts.
+ *
+ * monsoon_np_state = numpy.random.RandomState.get_state(legacy=False) of the GLOBAL stream the reference draws from
+ * (np.random.*): the mt19937 key, its position, and the cached second normal of legacy_gauss; in/out.
+ *
+ * monsoon_ga_offspring: Population.generate_offspring, evo/population.py:75-89 with WeightVector.copy / mutate,
+ * evo/weights.py:12-40: lambda offspring of parents[mu][dim] (weights, sigmas).  out_parent[lambda] = the parent drawn for
+ * each child, out_tries[lambda] = polar-method rounds consumed up to and including that child (both optional).  Every
+ * draw and every accept / reject decision is numpy's own, so the parents and the returned stream state (key, position,
+ * has_gauss) are bit-identical to the host's; exp / log / sqrt are the device library's, within 1 ulp of the host's,
+ * so weights and sigmas agree with the host's to a few ulp (tests/test_gpu_parity.py).
+ *
+ * monsoon_ga_select: the order of select_from_combined, evo/population.py:91-103: indices of all n individuals by
+ * descending fitness, equal fitness in original order (Python's stable sort with reverse=True). */
+typedef struct {
+  uint32_t key[624];
+  int32_t pos;        /* 0..624 (624 = the next draw regenerates the key) */
+  int32_t has_gauss;
+  double gauss;
+} monsoon_np_state;
+int monsoon_ga_offspring(monsoon_t* h, monsoon_np_state* st, const double* parents_w, const double* parents_s, int32_t mu, int32_t dim,
+                         int32_t lambda, double tau, double tau_prime, double min_sigma, double* out_w, double* out_s, int32_t* out_parent,
+                         int64_t* out_tries);
+int monsoon_ga_select(monsoon_t* h, const double* fitness, int32_t n, int32_t* out_order);
+
 /* Diagnostics: 192 raw counter words (words 0-4 back monsoon_get_stats; a profiling build (-DMSB_PROF=1,
  * scripts only) adds k_decide phase cycles at 8..15, per-function cycles / calls at 32..63 / 64..95, last-launch
  * occupancy at 96..101 and call entry / exit cycles at 128..159 / 160..191; the rest is zero).

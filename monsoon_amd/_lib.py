@@ -41,6 +41,10 @@ class MonsoonError(RuntimeError):
 _libs = {}
 
 # name -> (restype, argtypes); every symbol declared in include/monsoon.h
+class NpState(ctypes.Structure):   # monsoon_np_state: numpy.random.RandomState.get_state() of the global stream
+    _fields_ = [("key", ctypes.c_uint32 * 624), ("pos", ctypes.c_int32), ("has_gauss", ctypes.c_int32), ("gauss", ctypes.c_double)]
+
+
 SIGNATURES = {
     "monsoon_create": (ctypes.c_int, [ctypes.POINTER(Config), ctypes.POINTER(ctypes.c_void_p)]),
     "monsoon_destroy": (None, [ctypes.c_void_p]),
@@ -75,6 +79,10 @@ SIGNATURES = {
                                        ctypes.c_void_p]),
     "monsoon_rollout_faults": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32]),
     "monsoon_draw_decks": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p]),
+    "monsoon_ga_offspring": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32,
+                                            ctypes.c_int32, ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_void_p, ctypes.c_void_p,
+                                            ctypes.c_void_p, ctypes.c_void_p]),
+    "monsoon_ga_select": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p]),
     "monsoon_upload_weights": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32]),
     "monsoon_assign_players": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
     "monsoon_decide_round_dev": (ctypes.c_int, [ctypes.c_void_p]),

@@ -463,6 +463,123 @@ __global__ void __launch_bounds__(64) k_draw_decks(int n, const uint32_t* seeds,
   if (over) atomicAdd(overrun, 1);
 }
 
+// ------------------------------------------------------------------------------------------------
+// GA operators.  The reference's (mu + lambda) step draws everything from ONE global numpy
+// stream (evo/population.py:75-89, evo/weights.py:12-40): per offspring randint(0, mu) picks the parent,
+// WeightVector.copy() constructs a fresh vector first -- `dim` uniforms that are thrown away --, then mutate() draws one
+// global normal, `dim` per-gene normals and `dim` steps.  The stream position after one offspring depends on its
+// rejections, so the operator is serial by nature: ONE lane walks the stream here (the other 63 idle; at lambda = 4 096
+// that is ~250 000 outputs).  What is bit-identical to numpy: every draw and every accept / reject decision, i.e. the
+// parents chosen and the state handed back (key, position, the cached second normal up to the last bits of log / sqrt).
+// What is not: exp / log / sqrt are the device library's (within 1 ulp of glibc's / numpy's SIMD exp): offspring agree
+// with the host's to a few ulp.  The host GA stays the default and the bit-exact path.
+// ------------------------------------------------------------------------------------------------
+struct NpStream {   // numpy's legacy RandomState over an mt19937 state held in LDS
+  MSB_AS_LDS uint32_t* key;
+  int pos;
+  int has_gauss;
+  double gauss;
+  long long tries;   // polar-method rounds so far (diagnostics: the accept / reject pattern)
+  __device__ uint32_t u32() {   // mt19937_next: regenerate at position 624, temper on the way out
+    if (pos == MT_N) {
+      int k;
+      for (k = 0; k < MT_N - MT_M; k++) key[k] = key[k + MT_M] ^ mt_mix(key[k], key[k + 1]);
+      for (; k < MT_N - 1; k++) key[k] = key[k + (MT_M - MT_N)] ^ mt_mix(key[k], key[k + 1]);
+      key[MT_N - 1] = key[MT_M - 1] ^ mt_mix(key[MT_N - 1], key[0]);
+      pos = 0;
+    }
+    return mt_temper(key[pos++]);
+  }
+  __device__ double next_double() {   // legacy_double
+    uint32_t a = u32() >> 5, b = u32() >> 6;
+    return ((double)a * 67108864.0 + (double)b) / 9007199254740992.0;
+  }
+  __device__ uint32_t interval(uint32_t max) {   // random_interval / buffered_bounded_masked_uint32
+    if (max == 0) return 0;
+    uint32_t mask = max;
+    mask |= mask >> 1;
+    mask |= mask >> 2;
+    mask |= mask >> 4;
+    mask |= mask >> 8;
+    mask |= mask >> 16;
+    uint32_t v;
+    do {
+      v = u32() & mask;
+    } while (v > max);
+    return v;
+  }
+  __device__ double gauss_next() {   // legacy_gauss (numpy/random/src/legacy/legacy-distributions.c): polar Box-Muller, one value cached
+    if (has_gauss) {
+      const double t = gauss;
+      has_gauss = 0;
+      gauss = 0.0;
+      return t;
+    }
+    double f, x1, x2, r2;
+    do {
+      x1 = 2.0 * next_double() - 1.0;
+      x2 = 2.0 * next_double() - 1.0;
+      r2 = x1 * x1 + x2 * x2;
+      tries++;
+    } while (r2 >= 1.0 || r2 == 0.0);
+    f = sqrt(-2.0 * log(r2) / r2);
+    gauss = f * x1;
+    has_gauss = 1;
+    return f * x2;
+  }
+};
+__global__ void __launch_bounds__(64) k_ga_offspring(uint32_t* key_io, int* pos_gauss_io /* pos, has_gauss */, double* gauss_io, const double* pw,
+                                                     const double* ps, int mu, int dim, int lambda, double tau, double tau_prime, double min_sigma,
+                                                     double* out_w, double* out_s, int* out_parent, long long* out_tries) {
+  __shared__ uint32_t key[MT_N];
+  for (int k = threadIdx.x; k < MT_N; k += 64) key[k] = key_io[k];
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    NpStream rs{(MSB_AS_LDS uint32_t*)key, pos_gauss_io[0], pos_gauss_io[1], gauss_io[0], 0};
+    for (int c = 0; c < lambda; c++) {
+      const int p = (int)rs.interval((uint32_t)(mu - 1));         // np.random.randint(0, mu)
+      for (int i = 0; i < dim; i++) (void)rs.next_double();        // parent.copy(): WeightVector(size) draws uniform(0, 1, size)
+      const double g = rs.gauss_next();                            // np.random.normal(0, 1)
+      double sig[16];
+      for (int i = 0; i < dim; i++) {                              // np.random.normal(0, 1, n); sigma' = max(sigma * exp(tau' g + tau z), eps)
+        const double z = 0.0 + 1.0 * rs.gauss_next();
+        const double a = tau_prime * g, b = tau * z;
+        double sv = ps[(size_t)p * dim + i] * exp(a + b);
+        sig[i] = sv > min_sigma ? sv : min_sigma;                  // np.maximum
+        if (sv != sv) sig[i] = sv;
+      }
+      for (int i = 0; i < dim; i++) {                              // w' = clip(w + normal(0, sigma'), 0, 1)
+        const double stepv = 0.0 + sig[i] * rs.gauss_next();
+        double w = pw[(size_t)p * dim + i] + stepv;
+        w = w < 0.0 ? 0.0 : (w > 1.0 ? 1.0 : w);
+        out_w[(size_t)c * dim + i] = w;
+        out_s[(size_t)c * dim + i] = sig[i];
+      }
+      out_parent[c] = p;
+      out_tries[c] = rs.tries;
+    }
+    pos_gauss_io[0] = rs.pos;
+    pos_gauss_io[1] = rs.has_gauss;
+    gauss_io[0] = rs.gauss;
+  }
+  __syncthreads();
+  for (int k = threadIdx.x; k < MT_N; k += 64) key_io[k] = key[k];
+}
+// (mu + lambda) selection, evo/population.py:91-103: sorted(zip(fitness, individuals), key=fitness, reverse=True)[:mu] -- CPython's
+// sort is stable and reverse keeps equal keys in their original order, so the rank of i is the number of j with a larger
+// fitness, or an equal one and a smaller index.  One thread per individual, O(n^2) compares (n <= a few thousand).
+__global__ void k_ga_select(const double* fitness, int n, int* out_order) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const double f = fitness[i];
+  int rank = 0;
+  for (int j = 0; j < n; j++) {
+    const double g = fitness[j];
+    rank += (g > f || (g == f && j < i)) ? 1 : 0;
+  }
+  out_order[rank] = i;
+}
+
 }  // namespace
 
 // ================================================================================================
@@ -811,6 +928,80 @@ int monsoon_draw_decks(monsoon_t* h, const uint32_t* seeds, int32_t n, const uin
     h->err = "monsoon_draw_decks: " + std::to_string(over) + " seed(s) needed more than 1248 outputs of their stream";
     return done(MONSOON_ERR_STATE);
   }
+  return done(MONSOON_OK);
+}
+
+int monsoon_ga_offspring(monsoon_t* h, monsoon_np_state* st, const double* parents_w, const double* parents_s, int32_t mu, int32_t dim,
+                         int32_t lambda, double tau, double tau_prime, double min_sigma, double* out_w, double* out_s, int32_t* out_parent,
+                         int64_t* out_tries) {
+  if (!h || !st || !parents_w || !parents_s || !out_w || !out_s || mu <= 0 || lambda <= 0 || dim <= 0 || dim > 16 || st->pos < 0 || st->pos > MT_N) {
+    if (h) h->err = "monsoon_ga_offspring: bad argument (1 <= dim <= 16, 0 <= state position <= 624)";
+    return MONSOON_ERR_ARG;
+  }
+  HIP_TRY(h, bind_device(h));
+  const size_t pb = (size_t)mu * dim * 8, ob = (size_t)lambda * dim * 8;
+  uint8_t* d = nullptr;   // one allocation: key | pos, has_gauss | gauss | parents w, s | out w, s | parent | tries
+  const size_t o_key = 0, o_pg = MT_N * 4, o_g = o_pg + 8, o_pw = o_g + 8, o_ps = o_pw + pb, o_ow = o_ps + pb, o_os = o_ow + ob, o_par = o_os + ob,
+               o_tr = (o_par + (size_t)lambda * 4 + 7) & ~(size_t)7, total = o_tr + (size_t)lambda * 8;
+  HIP_TRY(h, hipMalloc(&d, total));
+  auto done = [&](int rc) {
+    hipFree(d);
+    return rc;
+  };
+#define GA_TRY(call)                                                  \
+  do {                                                                \
+    hipError_t e_ = (call);                                           \
+    if (e_ != hipSuccess) {                                           \
+      h->err = std::string(#call) + ": " + hipGetErrorString(e_);     \
+      return done(MONSOON_ERR_DEVICE);                                \
+    }                                                                 \
+  } while (0)
+  int pg[2] = {st->pos, st->has_gauss};
+  GA_TRY(hipMemcpyAsync(d + o_key, st->key, MT_N * 4, hipMemcpyHostToDevice, h->stream));
+  GA_TRY(hipMemcpyAsync(d + o_pg, pg, 8, hipMemcpyHostToDevice, h->stream));
+  GA_TRY(hipMemcpyAsync(d + o_g, &st->gauss, 8, hipMemcpyHostToDevice, h->stream));
+  GA_TRY(hipMemcpyAsync(d + o_pw, parents_w, pb, hipMemcpyHostToDevice, h->stream));
+  GA_TRY(hipMemcpyAsync(d + o_ps, parents_s, pb, hipMemcpyHostToDevice, h->stream));
+  hipLaunchKernelGGL(k_ga_offspring, dim3(1), dim3(64), 0, h->stream, (uint32_t*)(d + o_key), (int*)(d + o_pg), (double*)(d + o_g),
+                     (const double*)(d + o_pw), (const double*)(d + o_ps), mu, dim, lambda, tau, tau_prime, min_sigma, (double*)(d + o_ow),
+                     (double*)(d + o_os), (int*)(d + o_par), (long long*)(d + o_tr));
+  GA_TRY(hipGetLastError());
+  GA_TRY(hipMemcpyAsync(st->key, d + o_key, MT_N * 4, hipMemcpyDeviceToHost, h->stream));
+  GA_TRY(hipMemcpyAsync(pg, d + o_pg, 8, hipMemcpyDeviceToHost, h->stream));
+  GA_TRY(hipMemcpyAsync(&st->gauss, d + o_g, 8, hipMemcpyDeviceToHost, h->stream));
+  GA_TRY(hipMemcpyAsync(out_w, d + o_ow, ob, hipMemcpyDeviceToHost, h->stream));
+  GA_TRY(hipMemcpyAsync(out_s, d + o_os, ob, hipMemcpyDeviceToHost, h->stream));
+  if (out_parent) GA_TRY(hipMemcpyAsync(out_parent, d + o_par, (size_t)lambda * 4, hipMemcpyDeviceToHost, h->stream));
+  if (out_tries) GA_TRY(hipMemcpyAsync(out_tries, d + o_tr, (size_t)lambda * 8, hipMemcpyDeviceToHost, h->stream));
+  GA_TRY(hipStreamSynchronize(h->stream));
+  st->pos = pg[0];
+  st->has_gauss = pg[1];
+  return done(MONSOON_OK);
+}
+
+int monsoon_ga_select(monsoon_t* h, const double* fitness, int32_t n, int32_t* out_order) {
+  if (!h || !fitness || !out_order || n <= 0) {
+    if (h) h->err = "monsoon_ga_select: bad argument";
+    return MONSOON_ERR_ARG;
+  }
+  for (int i = 0; i < n; i++)
+    if (fitness[i] != fitness[i]) {
+      h->err = "monsoon_ga_select: NaN fitness (Python's sort order would be undefined)";
+      return MONSOON_ERR_ARG;
+    }
+  HIP_TRY(h, bind_device(h));
+  uint8_t* d = nullptr;
+  HIP_TRY(h, hipMalloc(&d, (size_t)n * 12));
+  auto done = [&](int rc) {
+    hipFree(d);
+    return rc;
+  };
+  GA_TRY(hipMemcpyAsync(d, fitness, (size_t)n * 8, hipMemcpyHostToDevice, h->stream));
+  hipLaunchKernelGGL(k_ga_select, dim3((n + 255) / 256), dim3(256), 0, h->stream, (const double*)d, n, (int*)(d + (size_t)n * 8));
+  GA_TRY(hipGetLastError());
+  GA_TRY(hipMemcpyAsync(out_order, d + (size_t)n * 8, (size_t)n * 4, hipMemcpyDeviceToHost, h->stream));
+  GA_TRY(hipStreamSynchronize(h->stream));
+#undef GA_TRY
   return done(MONSOON_OK);
 }
 

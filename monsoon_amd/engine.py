@@ -231,6 +231,37 @@ class BatchEngine:
             self._ck(self.lib.monsoon_draw_decks(self.h, _ptr(seeds), len(seeds), _ptr(pool), len(pool), _ptr(out)), "monsoon_draw_decks")
         return out
 
+    # ---- GA operators on the device (the host GA stays the default) -------------------------
+    def ga_offspring(self, np_state, parents_w, parents_s, n_offspring, tau, tau_prime, min_sigma):
+        """Population.generate_offspring on the device over numpy's global stream.  np_state: RandomState.get_state()
+        (legacy tuple or dict).  Returns (weights[n][dim], sigmas[n][dim], parent[n], tries[n], new_state) with new_state
+        in the form np.random.set_state accepts."""
+        from ._lib import NpState
+        if isinstance(np_state, dict):
+            key, pos, hg, g = np_state["state"]["key"], np_state["state"]["pos"], np_state["has_gauss"], np_state["gauss"]
+        else:
+            _, key, pos, hg, g = np_state
+        st = NpState()
+        key = np.ascontiguousarray(key, dtype=np.uint32)   # kept alive across the memmove
+        ctypes.memmove(st.key, key.ctypes.data, 624 * 4)
+        st.pos, st.has_gauss, st.gauss = int(pos), int(hg), float(g)
+        pw = np.ascontiguousarray(parents_w, dtype=np.float64)
+        ps = np.ascontiguousarray(parents_s, dtype=np.float64)
+        mu, dim = pw.shape
+        ow, osg = np.zeros((n_offspring, dim)), np.zeros((n_offspring, dim))
+        par, tries = np.zeros(n_offspring, dtype=np.int32), np.zeros(n_offspring, dtype=np.int64)
+        self._ck(self.lib.monsoon_ga_offspring(self.h, ctypes.byref(st), _ptr(pw), _ptr(ps), mu, dim, n_offspring, float(tau), float(tau_prime),
+                                               float(min_sigma), _ptr(ow), _ptr(osg), _ptr(par), _ptr(tries)), "monsoon_ga_offspring")
+        new_key = np.ctypeslib.as_array(st.key).astype(np.uint32).copy()
+        return ow, osg, par, tries, ("MT19937", new_key, int(st.pos), int(st.has_gauss), float(st.gauss))
+
+    def ga_select(self, fitness):
+        """Indices of all individuals by descending fitness, ties in original order (select_from_combined's sort)."""
+        f = np.ascontiguousarray(fitness, dtype=np.float64)
+        out = np.zeros(len(f), dtype=np.int32)
+        self._ck(self.lib.monsoon_ga_select(self.h, _ptr(f), len(f), _ptr(out)), "monsoon_ga_select")
+        return out
+
     # ---- device-resident rounds (bench) -------------------------------------------------------
     def upload_weights(self, weights):
         weights = np.ascontiguousarray(weights, dtype=np.float64).reshape(-1, 10)

@@ -39,15 +39,17 @@ class EvolutionEngine:
         pop = self.population
         while not pop.should_terminate():
             t0 = time.time()
+            # config.ga_on_device: offspring and the selection order through monsoon_ga_* on the evaluator's engine
+            ga = self.fitness_evaluator._engine(0) if (self.config.ga_on_device and self._rollout_fn is None) else None
             everyone = pop.get_parents()
             if pop.generation > 0:
-                everyone = everyone + pop.generate_offspring()
+                everyone = everyone + pop.generate_offspring(engine=ga)
             scores = self.fitness_evaluator.evaluate_population(everyone, pop.generation)
             if pop.generation == 0:
                 pop.fitness_scores = scores
                 pop.generation += 1
             else:
-                pop.select_from_combined(everyone, scores)
+                pop.select_from_combined(everyone, scores, order=ga.ga_select(scores) if ga is not None else None)
             self._log_generation(time.time() - t0)
             if pop.generation % self.config.checkpoint_interval == 0:
                 self._save_checkpoint()

@@ -45,7 +45,22 @@ class Population:
         return self.individuals[:self.config.mu]
 
     # evo/population.py:75-89
-    def generate_offspring(self):
+    def generate_offspring(self, engine=None):
+        """engine: a BatchEngine -> the device operator (monsoon_ga_offspring) over the same global numpy stream: the same
+        parents, the same stream position afterwards, weights / sigmas within a few ulp (device exp / log).  Default and
+        bit-exact path: the host loop below."""
+        if engine is not None:
+            pw = np.stack([p.weights for p in self.individuals[:self.config.mu]])
+            ps = np.stack([p.sigmas for p in self.individuals[:self.config.mu]])
+            ow, osg, _, _, state = engine.ga_offspring(np.random.get_state(), pw, ps, self.config.lambda_, self.config.tau, self.config.tau_prime,
+                                                       self.config.min_sigma)
+            np.random.set_state(state)
+            children = []
+            for k in range(self.config.lambda_):   # no constructor call: WeightVector(size) would draw from the stream
+                v = WeightVector.__new__(WeightVector)
+                v.weights, v.sigmas, v.size = ow[k].copy(), osg[k].copy(), ow.shape[1]
+                children.append(v)
+            return children
         children = []
         for _ in range(self.config.lambda_):
             parent = self.individuals[np.random.randint(0, self.config.mu)]
@@ -55,10 +70,15 @@ class Population:
         return children
 
     # evo/population.py:91-176
-    def select_from_combined(self, all_individuals, fitness_scores):
+    def select_from_combined(self, all_individuals, fitness_scores, order=None):
+        """order: the ranking computed on the device (BatchEngine.ga_select: descending fitness, ties in original order) --
+        the same permutation Python's stable sort gives; None = sort here."""
         if len(all_individuals) != len(fitness_scores):
             raise ValueError(f"Individuals ({len(all_individuals)}) must match fitness scores ({len(fitness_scores)})")
-        ranked = sorted(zip(fitness_scores, all_individuals), key=lambda p: p[0], reverse=True)[:self.config.mu]
+        if order is not None:
+            ranked = [(fitness_scores[int(i)], all_individuals[int(i)]) for i in order[:self.config.mu]]
+        else:
+            ranked = sorted(zip(fitness_scores, all_individuals), key=lambda p: p[0], reverse=True)[:self.config.mu]
         self.fitness_scores = [p[0] for p in ranked]
         self.individuals = [p[1] for p in ranked]
         self.generation += 1
@@ -121,6 +141,45 @@ class Population:
         self.individuals = data["individuals"]
         self.fitness_scores = data["fitness_scores"]
         self.config = data["config"]
+
+    def save_reference_checkpoint(self, filepath):
+        """The same checkpoint in the REFERENCE's own class names: a pickle that evo/population.py:295-310
+        (Population.load_population) of an unmodified reference loads -- {generation, individuals, fitness_scores, config}
+        with individuals of class evo.weights.WeightVector ({weights, sigmas, size}) and a config of class
+        evo.config.EvolutionaryConfig (the reference's field names; this build's extra fields ride along as attributes).
+        Nothing of the reference is imported: stand-in classes carrying the reference's module and class names exist only
+        while the pickle is written (pickle records names, not code)."""
+        import sys
+        import types
+        mods = {}
+
+        def stand_in(module, name):
+            m = mods.setdefault(module, types.ModuleType(module))
+            cls = type(name, (object,), {"__module__": module})
+            setattr(m, name, cls)
+            return cls
+        WV, CFG = stand_in("evo.weights", "WeightVector"), stand_in("evo.config", "EvolutionaryConfig")
+        mods.setdefault("evo", types.ModuleType("evo"))
+
+        def conv(v):
+            o = WV.__new__(WV)
+            o.__dict__.update({"weights": np.array(v.weights, dtype=np.float64), "sigmas": np.array(v.sigmas, dtype=np.float64), "size": int(v.size)})
+            return o
+        cfg = CFG.__new__(CFG)
+        cfg.__dict__.update(self.config.to_dict())
+        data = {"generation": self.generation, "individuals": [conv(v) for v in self.individuals],
+                "fitness_scores": list(self.fitness_scores), "config": cfg}
+        saved = {k: sys.modules.get(k) for k in mods}
+        sys.modules.update(mods)
+        try:
+            with open(filepath, "wb") as f:
+                pickle.dump(data, f, protocol=4)
+        finally:
+            for k, v in saved.items():
+                if v is None:
+                    sys.modules.pop(k, None)
+                else:
+                    sys.modules[k] = v
 
     def __len__(self):
         return len(self.individuals)

@@ -509,6 +509,89 @@ int orc_draw_decks(const uint32_t* seeds, int n, const uint8_t* pool, int pool_n
   }
   return over;
 }
+// monsoon_ga_offspring on the CPU (evo/population.py:75-89, evo/weights.py:12-40 over numpy's legacy global stream): the same
+// walk of the stream as the device kernel, with the host's libm -- legacy_gauss calls libm's log and sqrt itself, so this
+// equals numpy bit for bit except for exp (numpy's array exp is a SIMD routine of its own).
+struct OrcNpState {
+  uint32_t key[624];
+  int32_t pos, has_gauss;
+  double gauss;
+};
+static uint32_t np_u32(OrcNpState& s) {
+  if (s.pos == MT_N) {
+    mt_twist(s.key);
+    s.pos = 0;
+  }
+  return mt_temper(s.key[s.pos++]);
+}
+static double np_double(OrcNpState& s) {
+  uint32_t a = np_u32(s) >> 5, b = np_u32(s) >> 6;
+  return ((double)a * 67108864.0 + (double)b) / 9007199254740992.0;
+}
+static double np_gauss(OrcNpState& s, long long& tries) {
+  if (s.has_gauss) {
+    const double t = s.gauss;
+    s.has_gauss = 0;
+    s.gauss = 0.0;
+    return t;
+  }
+  double f, x1, x2, r2;
+  do {
+    x1 = 2.0 * np_double(s) - 1.0;
+    x2 = 2.0 * np_double(s) - 1.0;
+    r2 = x1 * x1 + x2 * x2;
+    tries++;
+  } while (r2 >= 1.0 || r2 == 0.0);
+  f = sqrt(-2.0 * log(r2) / r2);
+  s.gauss = f * x1;
+  s.has_gauss = 1;
+  return f * x2;
+}
+void orc_ga_offspring(OrcNpState* st, const double* pw, const double* ps, int mu, int dim, int lambda, double tau, double tau_prime,
+                      double min_sigma, double* out_w, double* out_s, int32_t* out_parent, int64_t* out_tries) {
+  OrcNpState& s = *st;
+  long long tries = 0;
+  for (int c = 0; c < lambda; c++) {
+    uint32_t max = (uint32_t)(mu - 1), mask = max, v = 0;
+    mask |= mask >> 1; mask |= mask >> 2; mask |= mask >> 4; mask |= mask >> 8; mask |= mask >> 16;
+    if (max) do { v = np_u32(s) & mask; } while (v > max);
+    const int p = (int)v;
+    for (int i = 0; i < dim; i++) (void)np_double(s);
+    const double g = np_gauss(s, tries);
+    double sig[16];
+    for (int i = 0; i < dim; i++) {
+      const double z = 0.0 + 1.0 * np_gauss(s, tries);
+      const double a = tau_prime * g, b = tau * z;
+      double sv = ps[(size_t)p * dim + i] * exp(a + b);
+      sig[i] = sv > min_sigma ? sv : min_sigma;
+      if (sv != sv) sig[i] = sv;
+    }
+    for (int i = 0; i < dim; i++) {
+      const double stepv = 0.0 + sig[i] * np_gauss(s, tries);
+      double w = pw[(size_t)p * dim + i] + stepv;
+      w = w < 0.0 ? 0.0 : (w > 1.0 ? 1.0 : w);
+      out_w[(size_t)c * dim + i] = w;
+      out_s[(size_t)c * dim + i] = sig[i];
+    }
+    if (out_parent) out_parent[c] = p;
+    if (out_tries) out_tries[c] = tries;
+  }
+}
+// n values of RandomState(seed).normal(0, 1) and the number of stream outputs consumed after each (624 = a freshly seeded stream's position)
+void orc_np_gauss(uint32_t seed, int n, double* values, int64_t* stream_pos) {
+  OrcNpState s;
+  mt_seed(s.key, seed);
+  s.pos = MT_N;
+  s.has_gauss = 0;
+  s.gauss = 0.0;
+  long long tries = 0, blocks = 0;
+  for (int i = 0; i < n; i++) {
+    const int before = s.pos;
+    values[i] = 0.0 + 1.0 * np_gauss(s, tries);
+    if (s.pos < before || (before == MT_N && s.pos != MT_N)) blocks++;
+    stream_pos[i] = (blocks - 1) * MT_N + s.pos + MT_N;
+  }
+}
 #if defined(MSB_COUNT_FRAMES)
 long long* orc_frame_counts() { return msb_frame_count; }   // study build (scripts/frame_stats.py)
 #endif

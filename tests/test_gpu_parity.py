@@ -930,3 +930,48 @@ def test_config_c5_one_generation_full_size():
           f"tiers {hip.tier_games}, {hip.capacity_replays} replayed, {left} left on a record limit, {deep} ended by the recursion guard")
     assert left == hip.capacity_faults and deep == hip.depth_faults
     assert left <= 524288 // 2000   # 0.05 %: nested copies beyond 254 entity objects
+
+
+def test_ga_operators_on_device(engines, gold):
+    """Population.generate_offspring (evo/population.py:75-89, evo/weights.py:12-40) and the selection order
+    on the device.  Against the host GA run by numpy itself (tests/golden/ga_kat.npz) and against the CPU restatement: the
+    parents drawn, the polar-method rounds behind every child (the accept / reject pattern: 1 024 children x 21 normals)
+    and the stream state handed back -- key, position, has_gauss -- are IDENTICAL; sigmas within 4 ulp, weights within
+    1e-15 (exp / log / sqrt are the device library's).  Then a host GA generation and a device one from the same numpy
+    state leave numpy's global stream in the same state."""
+    from test_oracle_golden import orc_ga, ulps
+    g = gold("ga_kat.npz")
+    eng = engines(64)
+    worst_s = worst_w = 0.0
+    for tag in ("a", "b"):
+        mu, lam, dim = (int(x) for x in g[f"{tag}_cfg"])
+        tau, taup, mins = (float(x) for x in g[f"{tag}_params"])
+        st0 = ("MT19937", g[f"{tag}_st0_key"], int(g[f"{tag}_st0_pos"][0]), int(g[f"{tag}_st0_pos"][1]), float(g[f"{tag}_st0_gauss"][0]))
+        ow, osg, par, tries, st1 = eng.ga_offspring(st0, g[f"{tag}_pw"], g[f"{tag}_ps"], lam, tau, taup, mins)
+        o_w, o_s, o_par, o_tries, o_key, o_pos, o_hg, o_g = orc_ga(g, tag)
+        assert np.array_equal(par, o_par) and np.array_equal(tries, o_tries)
+        assert np.array_equal(st1[1], g[f"{tag}_st1_key"]) and [st1[2], st1[3]] == g[f"{tag}_st1_pos"].tolist()
+        assert ulps([st1[4]], g[f"{tag}_st1_gauss"]).max() <= 4
+        worst_s = max(worst_s, float(ulps(osg, g[f"{tag}_ks"]).max()))
+        worst_w = max(worst_w, float(np.abs(ow - g[f"{tag}_kw"]).max()))
+    assert worst_s <= 4 and worst_w <= 1e-15, (worst_s, worst_w)
+    print(f"device GA offspring vs numpy: sigmas within {worst_s:.0f} ulp, weights within {worst_w:.2e}")
+    # the wrapper: numpy's global stream ends in the same state whichever side mutates
+    from monsoon_amd.config import EvolutionaryConfig
+    from monsoon_amd.population import Population
+    states = []
+    for use_device in (False, True):
+        pop = Population(EvolutionaryConfig(mu=64, lambda_=256, seed=123))
+        pop.initialize_population(10)
+        kids = pop.generate_offspring(engine=eng if use_device else None)
+        st = np.random.get_state()
+        states.append((st[1].copy(), st[2], st[3], np.stack([k.weights for k in kids]), np.stack([k.sigmas for k in kids])))
+    (k0, p0, h0, w0, s0), (k1, p1, h1, w1, s1) = states
+    assert np.array_equal(k0, k1) and (p0, h0) == (p1, h1)
+    assert np.abs(w0 - w1).max() <= 1e-15 and ulps(s0, s1).max() <= 4
+    # selection order = Python's stable sort, reverse=True (evo/population.py:98-103), ties included
+    rs = np.random.RandomState(4)
+    fit = np.round(rs.uniform(0, 1, 3000), 2)   # many ties
+    order = eng.ga_select(fit)
+    want = [i for _, i in sorted(zip(fit.tolist(), range(len(fit))), key=lambda p: p[0], reverse=True)]
+    assert order.tolist() == want

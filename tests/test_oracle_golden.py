@@ -295,3 +295,58 @@ def test_deck_draw_restatement_vs_numpy(gold):
     assert np.array_equal(oracle_draw_decks(g["seeds"], g["pool"]), g["pairs"])
     seeds = np.arange(300, dtype=np.uint32) * np.uint32(40503) + np.uint32(17)
     assert np.array_equal(oracle_draw_decks(seeds, observable_pool()), draw_random_decks_numpy(seeds))
+
+
+def ulps(a, b):
+    """Distance in units of the last place between float64 arrays (same sign assumed where it matters)."""
+    a = np.ascontiguousarray(a, dtype=np.float64).view(np.int64)
+    b = np.ascontiguousarray(b, dtype=np.float64).view(np.int64)
+    return np.abs(a - b)
+
+
+def orc_ga(g, tag):
+    """The oracle's restatement of Population.generate_offspring on fixture case `tag` -> (w, s, parent, tries, key, pos, has_gauss, gauss)."""
+    import ctypes
+
+    class St(ctypes.Structure):
+        _fields_ = [("key", ctypes.c_uint32 * 624), ("pos", ctypes.c_int32), ("has_gauss", ctypes.c_int32), ("gauss", ctypes.c_double)]
+    L = oracle_lib.lib()
+    mu, lam, dim = (int(x) for x in g[f"{tag}_cfg"])
+    tau, taup, mins = (float(x) for x in g[f"{tag}_params"])
+    st = St()
+    key0 = np.ascontiguousarray(g[f"{tag}_st0_key"], dtype=np.uint32)   # kept alive across the memmove
+    ctypes.memmove(st.key, key0.ctypes.data, 624 * 4)
+    st.pos, st.has_gauss, st.gauss = int(g[f"{tag}_st0_pos"][0]), int(g[f"{tag}_st0_pos"][1]), float(g[f"{tag}_st0_gauss"][0])
+    pw, ps = np.ascontiguousarray(g[f"{tag}_pw"]), np.ascontiguousarray(g[f"{tag}_ps"])
+    ow, osg = np.zeros((lam, dim)), np.zeros((lam, dim))
+    par, tries = np.zeros(lam, dtype=np.int32), np.zeros(lam, dtype=np.int64)
+    L.orc_ga_offspring.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_double,
+                                   ctypes.c_double, ctypes.c_double, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+    L.orc_ga_offspring.restype = None
+    p = oracle_lib._p
+    L.orc_ga_offspring(ctypes.byref(st), p(pw), p(ps), mu, dim, lam, tau, taup, mins, p(ow), p(osg), p(par), p(tries))
+    return ow, osg, par, tries, np.ctypeslib.as_array(st.key).copy(), st.pos, st.has_gauss, st.gauss
+
+
+def test_ga_offspring_restatement_vs_numpy(gold):
+    """the restatement of generate_offspring (randint parent, the copy's discarded uniforms, legacy_gauss with
+    its cache, the self-adaptive mutation) against the host GA run by numpy itself (tests/golden/ga_kat.npz): the stream
+    state afterwards -- key, position, has_gauss -- is numpy's, i.e. every draw and every accept / reject decision of the
+    polar method (1 024 children x 21 normals) was the same; children within 2 ulp (numpy's array exp is its own SIMD
+    routine).  And 20 000 raw normal(0, 1) values with the stream position behind each."""
+    import ctypes
+    g = gold("ga_kat.npz")
+    for tag in ("a", "b"):
+        ow, osg, par, tries, key, pos, hg, gs = orc_ga(g, tag)
+        assert np.array_equal(key, g[f"{tag}_st1_key"]) and [pos, hg] == g[f"{tag}_st1_pos"].tolist()
+        assert ulps([gs], g[f"{tag}_st1_gauss"]).max() == 0
+        # sigma' = sigma * exp(..): 2 ulp; w' = w + sigma' * z: a few ulp of the STEP, which can be many ulp of a small w'
+        assert ulps(osg, g[f"{tag}_ks"]).max() <= 2 and np.abs(ow - g[f"{tag}_kw"]).max() <= 4e-16
+        assert par.min() >= 0 and par.max() < int(g[f"{tag}_cfg"][0]) and (np.diff(tries) >= 10).all()
+    n = len(g["gauss_values"])
+    vals, pos = np.zeros(n), np.zeros(n, dtype=np.int64)
+    L = oracle_lib.lib()
+    L.orc_np_gauss.argtypes = [ctypes.c_uint32, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+    L.orc_np_gauss.restype = None
+    L.orc_np_gauss(int(g["gauss_seed"][0]), n, oracle_lib._p(vals), oracle_lib._p(pos))
+    assert np.array_equal(pos, g["gauss_stream_pos"]) and ulps(vals, g["gauss_values"]).max() == 0

@@ -34,3 +34,37 @@ def test_random_policy_games_equal_the_reference_step_by_step(args, ext):
     bad = [ln for ln in tail if ln.startswith("MISMATCH") and not any(f"ours faulted ({c})" in ln for c in (16, 22, 23))]
     assert not bad, bad
     assert tail and " games, " in tail[-1], tail
+
+
+def test_reference_loads_the_exported_checkpoint(tmp_path):
+    """SURVEY §8f rank 4, checkpoint compatibility: Population.save_reference_checkpoint writes a pickle in the reference's own
+    class names; the UNMODIFIED reference (evo/population.py:295-310) loads it and finds the same generation, fitness
+    scores, weights and sigmas, and can go on mutating the individuals with its own WeightVector.mutate."""
+    import numpy as np
+    sys.path.insert(0, REPO)
+    from monsoon_amd.config import EvolutionaryConfig
+    from monsoon_amd.population import Population
+    pop = Population(EvolutionaryConfig(mu=12, lambda_=12, seed=9))
+    pop.initialize_population(10)
+    pop.fitness_scores = [i / 12 for i in range(12)]
+    pop.generation = 7
+    path = str(tmp_path / "population.pkl")
+    pop.save_reference_checkpoint(path)
+    assert "evo.weights" not in sys.modules and "evo.config" not in sys.modules   # the stand-ins are gone again
+    np.save(str(tmp_path / "w.npy"), np.stack([v.weights for v in pop.individuals]))
+    np.save(str(tmp_path / "s.npy"), np.stack([v.sigmas for v in pop.individuals]))
+    code = (
+        "import sys, numpy as np; sys.path.insert(0, %r); import refenv; refenv.setup();"
+        "from evo.config import EvolutionaryConfig; from evo.population import Population; import evo.weights;"
+        "p = Population(EvolutionaryConfig()); p.load_population(%r);"
+        "assert p.generation == 7 and len(p.individuals) == 12 and p.fitness_scores[11] == 11 / 12;"
+        "assert all(type(v) is evo.weights.WeightVector for v in p.individuals) and type(p.config) is EvolutionaryConfig;"
+        "assert np.array_equal(np.stack([v.get_weights() for v in p.individuals]), np.load(%r));"
+        "assert np.array_equal(np.stack([v.get_sigmas() for v in p.individuals]), np.load(%r));"
+        "assert p.config.mu == 12 and p.config.tau == 0.1;"
+        "c = p.individuals[3].copy(); c.mutate(p.config.tau, p.config.tau_prime, p.config.min_sigma); assert c.size == 10;"
+        "print('loaded by the reference')"
+    ) % (os.path.join(REPO, "oracle", "pyref"), path, str(tmp_path / "w.npy"), str(tmp_path / "s.npy"))
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, PYTHONHASHSEED="0", PYTHONDONTWRITEBYTECODE="1"), capture_output=True,
+                       text=True, timeout=300)
+    assert r.returncode == 0 and "loaded by the reference" in r.stdout, r.stderr[-2000:]
