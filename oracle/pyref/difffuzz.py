@@ -23,7 +23,11 @@ from evo.features import StateFeatures  # noqa: E402
 
 BUILD = int(os.environ.get("MSB_EXT", "0"))   # MSB_EXT=1: extended record (ua20, b005); MSB_EXT=2: the large record
 EXT = BUILD >= 1
-LIB = ctypes.CDLL(os.path.join(H.REPO, "oracle", ("liboracle.so", "liboracle_ext.so", "liboracle_big.so")[BUILD]))
+# MSB_CORE=product: the host build of the PRODUCT's rules core (explicit work stack) instead of the recursive oracle -- the
+# same C entry points over the other implementation (oracle/Makefile)
+CORE = os.environ.get("MSB_CORE", "oracle")
+LIB = ctypes.CDLL(os.path.join(H.REPO, "oracle", {"oracle": ("liboracle.so", "liboracle_ext.so", "liboracle_big.so"),
+                                                  "product": ("libproduct_host.so", "libproduct_host_ext.so", "libproduct_host_big.so")}[CORE][BUILD]))
 LIB.orc_create.restype = ctypes.c_void_p
 LIB.orc_canon_hash.restype = ctypes.c_uint64
 for name in ("orc_reset", "orc_legal", "orc_step", "orc_observe", "orc_features", "orc_canon", "orc_destroy",

@@ -42,7 +42,7 @@ def main():
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--must", default="")
     ap.add_argument("--max-steps", type=int, default=400)
-    ap.add_argument("--core", default="product", help="product | product_evict (host build with the device's 24-word resident stack)")
+    ap.add_argument("--core", default="product", help="product | product_evict (host build with the device's 21-word resident stack)")
     a = ap.parse_args()
     rs = np.random.RandomState(a.seed)
     ids = pool_ids(a.pool, a.tier)

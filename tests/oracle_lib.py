@@ -16,7 +16,7 @@ LIB_PATH_BIG = os.path.join(ORACLE_DIR, "liboracle_big.so")   # large extended r
 # host builds of the PRODUCT's rules core (explicit work stack; oracle/oracle.cpp -DORC_PRODUCT_CORE): the same C entry
 # points over the other implementation of the rules, for the CPU-side checks of the product core
 PRODUCT_HOST = tuple(os.path.join(ORACLE_DIR, n) for n in ("libproduct_host.so", "libproduct_host_ext.so", "libproduct_host_big.so"))
-# ... and with the device's 24-word resident work stack, so that the eviction path of wk_reserve runs on the CPU too
+# ... and with the device's 21-word resident work stack, so that the eviction path of wk_reserve runs on the CPU too
 PRODUCT_HOST_EVICT = tuple(os.path.join(ORACLE_DIR, n) for n in ("libproduct_host_evict.so", "libproduct_host_evict_ext.so"))
 
 
@@ -27,7 +27,8 @@ def build():
 _libs = {}
 
 
-def lib(extended=False, core="oracle"):
+def lib(extended=False, core=None):
+    core = core or os.environ.get("MSB_ORACLE_CORE", "oracle")   # "product": the host build of the product's rules core
     key = (extended, core)
     if key not in _libs:
         paths = {"product": PRODUCT_HOST, "product_evict": PRODUCT_HOST_EVICT}.get(core, (LIB_PATH, LIB_PATH_EXT, LIB_PATH_BIG))
@@ -88,7 +89,7 @@ class Oracle:
     def __init__(self, n=1, extended=False, core=None):
         # core: "oracle" (the recursive restatement, the checker) or "product" (host build of the product's rules core);
         # MSB_ORACLE_CORE=product switches the default, which runs the whole golden suite over the product core
-        self.L = lib(extended, core or os.environ.get("MSB_ORACLE_CORE", "oracle"))
+        self.L = lib(extended, core)
         self.h = ctypes.c_void_p(self.L.orc_create(n))
         self.n = n
 

@@ -6,6 +6,16 @@ import pytest
 import oracle_lib
 
 
+@pytest.fixture(autouse=True, params=["oracle", "product"])
+def rules_core(request, monkeypatch):
+    """Every test of this module runs twice: over the ORACLE (oracle/recursive/: the reference's call structure kept) and over
+    the host build of the PRODUCT's rules core (monsoon_amd/csrc/rules.h: the explicit work stack the HIP kernels run).  Both
+    must reproduce the reference's fixtures; oracle_lib.Oracle picks the library by this environment variable."""
+    monkeypatch.setenv("MSB_ORACLE_CORE", request.param)
+    return request.param
+
+
+
 def _p(a):
     return a.ctypes.data_as(__import__("ctypes").c_void_p)
 
