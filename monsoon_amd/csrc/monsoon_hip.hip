@@ -1179,17 +1179,16 @@ int monsoon_state_load(monsoon_t* h, int32_t idx, const uint8_t* buf, int32_t bu
     return MONSOON_ERR_ARG;
   }
   // The blob carries the game's bookkeeping row as it was in the handle that saved it.  What refers to THAT handle is
-  // checked or reset here: a stream cursor outside its two resident blocks is refused; the players' weight rows are
-  // kept only if this handle's weight table has them (else both become row 0 -- assign players again before deciding),
-  // and the schedule index, which only the rollout that set it may use, is cleared.
+  // checked here: a stream cursor outside its two resident blocks is refused; the players' weight rows are kept only if
+  // this handle's weight table has them (else both become row 0 -- assign players again before deciding).  The schedule
+  // index travels along untouched: only monsoon_rollout reads it, after it has reset every game and set it anew.
   GameMeta gm;
   memcpy(&gm, buf + 8, sizeof(gm));
   if ((gm.rng & 0xffffu) >= (uint32_t)(2 * MT_N) || (gm.rng >> 17) != 0) {
     h->err = "monsoon_state_load: the blob's stream cursor is out of range";
     return MONSOON_ERR_ARG;
   }
-  if (gm.p1 < 0 || gm.p2 < 0 || gm.p1 >= h->n_individuals || gm.p2 >= h->n_individuals) gm.p1 = gm.p2 = 0;
-  gm.match = 0;
+  if (gm.p1 < 0 || gm.p2 < 0 || (h->b.weights && (gm.p1 >= h->n_individuals || gm.p2 >= h->n_individuals))) gm.p1 = gm.p2 = 0;
   std::vector<uint8_t> staged(buf, buf + BLOB_BYTES);
   memcpy(staged.data() + 8, &gm, sizeof(gm));
   HIP_TRY(h, bind_device(h));
