@@ -24,13 +24,17 @@ constexpr int NUM_ENT = MSB_CAP_ENT;   // capacity studies (scripts/c5_capacity.
 #elif defined(MSB_EXT) && MSB_EXT == 2
 constexpr int NUM_ENT = 254;  // the LARGE record: every slot id a byte can name (0xFE / 0xFF are markers)
 #elif defined(MSB_EXT) && MSB_EXT
-constexpr int NUM_ENT = 128;  // 20 tiles + transient + b005's remembered copies + the entities of frozen world snapshots
+// 20 tiles + transient + b005's remembered copies + the entities of frozen world snapshots.  Round 3: 64 slots (2 832-byte record)
+// instead of 128 (4 240): 8 instead of 4 candidate lanes fit a wavefront's LDS and the extended tier of a C5 generation runs 1.4x
+// faster; 0.9 % instead of 0.2 % of random-deck games then need the large record (scripts/c5_capacity.py --ent 64), which the
+// ladder gives them.
+constexpr int NUM_ENT = 64;
 #else
 // 20 tiles + 4 transient (dead / displaced / spawned this step).  Round 3: 24 instead of 28 -- a 752-byte record, which
 // together with the best successor parked in HBM lets 20 instead of 17 wavefronts share a CU's LDS.  No step of 68 000
 // heuristic games on five deck families (N12M, S12, N12V, Ironclad vs Swarm, 20 000 random 107-card deck pairs) needs a
 // 25th slot (22 slots: one game does, 21: 30 games; scripts/capacity_standard.py); a game that ever does reports
-// FAULT_CAPACITY and the rollout path plays it again on the extended record (128 slots), like any other record limit.
+// FAULT_CAPACITY and the rollout path plays it again on the extended record (64 slots), like any other record limit.
 constexpr int NUM_ENT = 24;
 #endif
 constexpr int HAND_CAP = 5;    // 4, transiently 5 (b305 returns itself to hand)

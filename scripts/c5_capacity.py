@@ -39,7 +39,7 @@ def main():
     d = os.path.join(REPO, "oracle", "_cap")
     os.makedirs(d, exist_ok=True)
     path = os.path.join(d, f"liboracle_{args.ext}_{args.ent}_{args.rem}_{args.world}.so")
-    flags = "-O2 -std=c++17 -fPIC -ffp-contract=off -fno-strict-aliasing -fno-fast-math -Wno-psabi".split()
+    flags = "-O2 -std=c++17 -fPIC -ffp-contract=off -fno-strict-aliasing -fno-fast-math -Wno-psabi".split() + ["-I" + os.path.join(REPO, "monsoon_amd", "csrc")]
     subprocess.run(["g++", *flags, f"-DMSB_EXT={args.ext}", f"-DMSB_CAP_REM={args.rem}", f"-DMSB_CAP_WORLD={args.world}", f"-DMSB_CAP_ENT={args.ent}", f"-DMSB_CAP_DEPTH={args.depth}", f"-DMSB_CAP_REMDEPTH={args.remdepth}", "-shared", "-o", path,
                     os.path.join(REPO, "oracle", "oracle.cpp"), "-lpthread"], check=True)
     pool = np.array([i for i, c in enumerate(CARD_IDS) if c not in ("up01", "up02", "up03")], dtype=np.uint8)

@@ -16,6 +16,6 @@ def c5_games(indices):
     return m, pairs
 
 
-# C5 games (of the first 32 768, weight vector W0) whose nested b005 memories do not fit the extended record's 128 entity
+# C5 games (of the first 32 768, weight vector W0) whose nested b005 memories did not fit round 2's extended record of 128 entity
 # slots / 16 memory lists (scripts/c5_capacity.py); 2063 and 6149 do not fit the large record either
 C5_OVERFLOWING = [264, 1374, 2063, 2103, 2458, 2649, 3525, 3540, 3691, 4215, 4593, 5070, 6011, 6149, 6592, 7552, 8558, 9657, 10155, 10993]

@@ -288,7 +288,7 @@ def test_replay_tier_for_games_the_extended_record_cannot_hold():
     c2, r2, s2, f2 = oracle_rollout_tier(w, m, pairs, 200, 2)
     ct, rt, st, ft = oracle_rollout_fn(w, m, pairs, 200, want_faults=True)
     over = f1 >= 16
-    assert over[:10].sum() >= 9 and not over[10:].any()
+    assert over[:10].sum() >= 9 and over[10:].sum() <= 1
     assert np.array_equal(rt[over], r2[over]) and np.array_equal(st[over], s2[over]) and np.array_equal(ft[over], f2[over])
     assert np.array_equal(rt[~over], r1[~over]) and np.array_equal(st[~over], s1[~over]) and np.array_equal(ft[~over], f1[~over])
     assert np.array_equal(r1[~over], r2[~over]) and np.array_equal(s1[~over], s2[~over])
