@@ -48,6 +48,17 @@ def _worker(rank, world, port, out_dir):
     ev2 = FitnessEvaluator(cfg, _deck_schedule(), rollout_fn=oracle_rollout_fn)
     f2 = ev2.evaluate_population(_population(), generation=3)
     np.save(os.path.join(out_dir, f"fitdeck{rank}.npy"), np.array(f2))
+    # configuration C5's per-game random decks depend on the game's seed alone: every rank draws only the decks of its shard
+    from oracle_rollout import oracle_draw_decks
+    drawn = []
+
+    def draw(seeds, pool):
+        drawn.append(len(seeds))
+        return oracle_draw_decks(seeds, pool)
+    cfg3 = EvolutionaryConfig(mu=4, lambda_=4, schedule="ring", games_per_individual=2, max_turns=10, deck="random109")
+    f3 = FitnessEvaluator(cfg3, rollout_fn=oracle_rollout_fn, deck_draw_fn=draw).evaluate_population(_population(), generation=3)
+    np.save(os.path.join(out_dir, f"fitrand{rank}.npy"), np.array(f3))
+    np.save(os.path.join(out_dir, f"drawn{rank}.npy"), np.array(drawn))
     dist.destroy_process_group()
 
 
@@ -66,6 +77,12 @@ def test_sharded_evaluation_matches_single_process(tmp_path):
     single_deck = FitnessEvaluator(cfg, _deck_schedule(), rollout_fn=oracle_rollout_fn).evaluate_population(_population(), generation=3)
     assert np.array_equal(d0, d1)
     assert np.array_equal(d0, np.array(single_deck))
+    from oracle_rollout import oracle_draw_decks
+    cfg3 = EvolutionaryConfig(mu=4, lambda_=4, schedule="ring", games_per_individual=2, max_turns=10, deck="random109")
+    single_rand = FitnessEvaluator(cfg3, rollout_fn=oracle_rollout_fn, deck_draw_fn=oracle_draw_decks).evaluate_population(_population(), generation=3)
+    r0, r1 = np.load(tmp_path / "fitrand0.npy"), np.load(tmp_path / "fitrand1.npy")
+    assert np.array_equal(r0, r1) and np.array_equal(r0, np.array(single_rand))
+    assert np.load(tmp_path / "drawn0.npy").tolist() == [4] and np.load(tmp_path / "drawn1.npy").tolist() == [4]   # 8 games, 4 per rank
 
 
 def _run_bench(args, env_extra):
