@@ -197,6 +197,12 @@ class FitnessEvaluator:
             self._engines[tier] = BatchEngine(games, device=dev, lanes_per_game=self.config.lanes_per_game if tier == 0 else 0, extended=tier)
         return self._engines[tier]
 
+    def warm_up(self):
+        """Create the standard-record engine now (device buffers for max_concurrent_games: ~0.9 s) instead of inside the
+        first evaluate_population call; the extended / large engines are still created when a schedule first needs them."""
+        if self._rollout_fn is None and self.config.mode == "rollout":
+            self._engine(0)
+
     def _hip_rollout(self, weights, matches, deck_pairs, max_turns):
         def play(tier, sub, sub_pairs):
             eng = self._engine(tier)
