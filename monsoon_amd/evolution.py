@@ -31,6 +31,7 @@ class EvolutionEngine:
         self.population = Population(self.config)
         self.population.initialize_population(FEATURE_COUNT)
         self.fitness_evaluator = FitnessEvaluator(self.config, self.deck_config, rollout_fn=self._rollout_fn)
+        self.fitness_evaluator.warm_up()   # device buffers are allocated here, not inside generation 0's evaluation
 
     def run(self):
         if self.population is None or self.fitness_evaluator is None:
