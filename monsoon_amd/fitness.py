@@ -198,10 +198,15 @@ class FitnessEvaluator:
         return self._engines[tier]
 
     def warm_up(self):
-        """Create the standard-record engine now (device buffers for max_concurrent_games: ~0.9 s) instead of inside the
-        first evaluate_population call; the extended / large engines are still created when a schedule first needs them."""
+        """Create the standard-record engine and launch once now instead of inside the first evaluate_population call; the
+        extended / large engines are still created when a schedule first needs them."""
         if self._rollout_fn is None and self.config.mode == "rollout":
-            self._engine(0)
+            eng = self._engine(0)
+            # one two-decision game: loads the code objects and sizes the launch-time buffers (0.7 s the first time)
+            from .cards import deck_indices
+            d = deck_indices("N12M")
+            eng.rollout(np.zeros((1, 10)), np.zeros(1, dtype=MATCH_DTYPE), np.stack([d, d])[None], 2)
+            eng.reset_stats()
 
     def _hip_rollout(self, weights, matches, deck_pairs, max_turns):
         def play(tier, sub, sub_pairs):

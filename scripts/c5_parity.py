@@ -1,6 +1,13 @@
 #!/usr/bin/env python3
-"""One-GPU slice of C5 at scale: N random-deck games (extended build) against the CPU replay (test infrastructure:
-uses oracle/ through tests/oracle_lib.py).  gpurun -- python scripts/c5_parity.py [N]"""
+"""Configuration C5 at scale against the CPU replay (test infrastructure: uses oracle/ through tests/oracle_rollout.py).
+
+    gpurun -- python scripts/c5_parity.py [individuals=4096] [games_per_individual=128]
+
+One generation through FitnessEvaluator.evaluate_population: per-game decks drawn on the device from the 109 observable
+cards (monsoon_draw_decks), every game on the smallest record its decks need, overflowing games replayed on the next larger
+one; then the same schedule on the 16-thread CPU replay (decks by the CPU restatement of the draw).  Prints the timings, the
+tiers and whether every fitness value, result, decision count and fault code agrees; exit status 1 on any difference.
+tests/test_gpu_parity.py::test_config_c5_one_generation_full_size is this at the default size."""
 import os
 import sys
 import time
@@ -10,60 +17,47 @@ import numpy as np
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO)
 sys.path.insert(0, os.path.join(REPO, "tests"))
-import oracle_lib  # noqa: E402
-from monsoon_amd.cards import CARD_IDS  # noqa: E402
-from monsoon_amd.engine import BatchEngine  # noqa: E402
+from oracle_rollout import oracle_draw_decks, oracle_rollout_fn_mt  # noqa: E402
+from monsoon_amd.cards import RANDOM_DECK  # noqa: E402
+from monsoon_amd.config import EvolutionaryConfig  # noqa: E402
+from monsoon_amd.fitness import FitnessEvaluator, record_limited  # noqa: E402
+from monsoon_amd.weights import WeightVector  # noqa: E402
 
-n = int(sys.argv[1]) if len(sys.argv) > 1 else 32768
-W0 = np.random.RandomState(2024).uniform(0, 1, 10)
-pool = np.array([i for i, c in enumerate(CARD_IDS) if c not in ("up01", "up02", "up03")], dtype=np.uint8)
-pairs = np.zeros((n, 2, 12), dtype=np.uint8)
-for g in range(n):
-    rs = np.random.RandomState(g ^ 0x9E3779B9)
-    pairs[g, 0], pairs[g, 1] = rs.choice(pool, 12, replace=False), rs.choice(pool, 12, replace=False)
-m = np.zeros(n, dtype=[("p1", "<i4"), ("p2", "<i4"), ("seed", "<u4"), ("deck", "<u4")])
-m["seed"] = 500000 + np.arange(n)
-m["deck"] = np.arange(n)
-eng = BatchEngine(n, extended=True)
+n_ind = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+gpi = int(sys.argv[2]) if len(sys.argv) > 2 else 128
+np.random.seed(11)
+pop = [WeightVector(10) for _ in range(n_ind)]
+cfg = EvolutionaryConfig(mu=n_ind, lambda_=n_ind, schedule="ring", games_per_individual=gpi, deck=RANDOM_DECK, max_turns=200, max_concurrent_games=65536)
+hip = FitnessEvaluator(cfg)
+hip.use_hall_of_fame = False
+hip.evaluate_population(pop[:min(64, n_ind)], generation=0)   # creates the engines of both tiers
+hip.reset_stats()
+hip.tier_games, hip.capacity_replays, hip.capacity_faults, hip.depth_faults = [0, 0], 0, 0, 0
 t0 = time.time()
-_, results, steps = eng.rollout(W0[None], m, pairs, 200, want_results=True)
-t1 = time.time()
-hashes, faults = eng.state_hash(), eng.game_faults()
-orc = oracle_lib.Oracle(n, extended=True)
-for g in range(n):
-    assert orc.reset(g, int(m["seed"][g]), pairs[g, 0], pairs[g, 1]) == 0
-t2 = time.time()
-total, ores, osteps, ohash = orc.rollout_batch(n, W0, 200, 16)
-t3 = time.time()
-bad = int((results != ores).sum() + (steps != osteps).sum() + (hashes != ohash).sum())
+f_hip = hip.evaluate_population(pop, generation=3)
+t_hip = time.time() - t0
+results, steps, faults = hip.last_rollout
+kms, launches = hip.kernel_time()
+box = {}
+
+
+def cpu_rollout(weights, matches, deck_pairs, max_turns):
+    box["rows"] = oracle_rollout_fn_mt(weights, matches, deck_pairs, max_turns, want_faults=True)
+    return box["rows"][0]
+
+
+cpu = FitnessEvaluator(cfg, rollout_fn=cpu_rollout, deck_draw_fn=oracle_draw_decks)
+cpu.use_hall_of_fame = False
+t0 = time.time()
+f_cpu = cpu.evaluate_population(pop, generation=3)
+t_cpu = time.time() - t0
+_, ores, osteps, of = box["rows"]
+bad = int((np.array(f_hip) != np.array(f_cpu)).sum() + (results != ores).sum() + (steps != osteps).sum() + (faults != of).sum())
+st = hip.get_stats()
 codes, cnt = np.unique(faults, return_counts=True)
-print(f"{n} random-deck games: GPU rollout {t1 - t0:.2f} s, CPU replay (16 threads) {t3 - t2:.2f} s, {total / 1e6:.1f} M env-steps, "
-      f"mismatching games {bad}, fault codes {dict(zip(codes.tolist(), cnt.tolist()))}")
-# the replay tier of monsoon_amd/fitness.py: games the extended record cannot hold, again on the large record -- and the
-# same on the CPU replay
-from monsoon_amd.fitness import replace_capacity_faulted  # noqa: E402
-from oracle_rollout import oracle_rollout_tier  # noqa: E402
-counts = np.zeros((1, 3), dtype=np.int64)
-counts[0] = [(results == 0).sum(), (results == -1).sum(), n]
-rf = eng.rollout_faults(n)
-assert np.array_equal(rf, faults)
-big = BatchEngine(2048, extended=2)
-
-
-def replay_hip(sub):
-    c, r, s = big.rollout(W0[None], sub, pairs, 200, want_results=True)
-    return c.astype(np.int64), r, s, big.rollout_faults(len(sub))
-
-
-t4 = time.time()
-k = replace_capacity_faulted(counts, results, steps, rf, m, replay_hip)
-t5 = time.time()
-ocounts = np.zeros((1, 3), dtype=np.int64)
-ocounts[0] = [(ores == 0).sum(), (ores == -1).sum(), n]
-of = np.array([orc.game_fault(g) for g in range(n)], dtype=np.uint8)
-replace_capacity_faulted(ocounts, ores, osteps, of, m, lambda sub: oracle_rollout_tier(W0[None], sub, pairs, 200, 2))
-bad2 = int((results != ores).sum() + (steps != osteps).sum() + (rf != of).sum() + (counts != ocounts).sum())
-codes, cnt = np.unique(rf, return_counts=True)
-print(f"replay tier: {k} games replayed on the large record in {t5 - t4:.2f} s, mismatching games {bad2}, "
-      f"fault codes after replay {dict(zip(codes.tolist(), cnt.tolist()))}")
-sys.exit(1 if bad or bad2 else 0)
+print(f"C5 generation, {n_ind} x {gpi} = {n_ind * gpi} games: GPU {t_hip:.2f} s end to end (k_play {kms / 1e3:.2f} s in {launches} launches, "
+      f"{st['env_steps'] / 1e6:.0f} M env-steps = {st['env_steps'] / t_hip / 1e6:.0f} M/s), CPU replay on 16 threads {t_cpu:.1f} s")
+print(f"  tiers: {hip.tier_games[0]} games on the standard record, {hip.tier_games[1]} on the extended one, {hip.capacity_replays} replayed on a larger "
+      f"record, {int(record_limited(faults).sum())} left on a record limit, {int((faults == 18).sum())} ended by the recursion guard")
+print(f"  fault codes {dict(zip(codes.tolist(), cnt.tolist()))}; rows that differ from the CPU replay: {bad}")
+sys.exit(1 if bad else 0)
