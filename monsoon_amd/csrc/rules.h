@@ -154,10 +154,14 @@ constexpr int MAX_DEPTH = MSB_CAP_DEPTH;   // capacity studies
 constexpr int MAX_DEPTH = 40;
 #endif
 
-// Which rules-core functions are inlined into their callers was settled by same-box A/B runs (scripts/ab_env.sh, scripts/ab_libs.sh)
-// measured (same-box A/B, 65 536 games): new_entity + set_path + calculate_front_line inlined +2.4 %;
-// entity_deal_damage inlined +0.6 %; player_play inlined -15 % in round 1's k_decide, +2 % in round 2's k_play (1 437-1 450 ->
-// 1 474 M env-steps/s; step_impl inlined as well: 1 462; to_next_turn inlined: 1 380; destroy inlined: 1 453)
+// Which rules-core functions are inlined into their callers was settled by same-box A/B runs (scripts/ab_env.sh,
+// scripts/ab_libs.sh; 65 536 games).  Rounds 1-2, on the recursive core: new_entity + set_path + calculate_front_line inlined
+// +2.4 %; get_targets +7.8 %, shape_targets +5 %, draw +1.2 %; shape_tiles, shuffle/sorted_head, legal_mask_v and the
+// command/teleport/push_pull/spawn helpers gained nothing and stay out of line; one non-inlined function per card instead of
+// one switch function +3 %.  Round 3, on the work-stack core: the handlers of the rare frames and the abilities that call
+// back into the core are out of line (they would otherwise sit inside run()'s loop and raise every lane's register count);
+// step_impl out of line 1 315 M env-steps/s against 1 277 inlined (DESIGN.md section 4 has the trade: 800 B of saved
+// registers per pass against 96 VGPRs).
 #ifndef MSB_A_NEWENT
 #define MSB_A_NEWENT MSB_INL
 #endif
@@ -167,28 +171,15 @@ constexpr int MAX_DEPTH = 40;
 #ifndef MSB_A_FRONT
 #define MSB_A_FRONT MSB_INL
 #endif
-#ifndef MSB_A_PLAY
-#define MSB_A_PLAY MSB_INL
-#endif
-// second batch: get_targets inlined +7.8 %, shape_targets +5 %, entity_deal_damage +1.6 %, draw +1.2 %, destroy -3 %
-#ifndef MSB_A_DAMAGE
-#define MSB_A_DAMAGE MSB_INL
-#endif
 #ifndef MSB_A_TARGETS
 #define MSB_A_TARGETS MSB_INL
 #endif
 #ifndef MSB_A_DRAW
 #define MSB_A_DRAW MSB_INL
 #endif
-#ifndef MSB_A_DESTROY
-#define MSB_A_DESTROY MSB_NOINLINE
-#endif
 #ifndef MSB_A_SHAPE
 #define MSB_A_SHAPE MSB_INL
 #endif
-// third batch (no gain, left out-of-line): shape_tiles +0.4 %, shuffle/sorted_head 0, legal_mask_v +0.2 %,
-// command/teleport/push_pull/force_attack/spawn/respawn +0.8 %; flip + to_next_turn inlined -8.5 %, ability_spell -18 %.
-// One non-inlined function per card instead of one switch function (abilities.inc): +3 %.
 // handlers of the rare frames, abilities with nested calls: out of line
 #ifndef MSB_A_RARE
 #define MSB_A_RARE MSB_NOINLINE
