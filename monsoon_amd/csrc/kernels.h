@@ -333,6 +333,22 @@ __device__ MSB_INL void play_game(const DevBuffers& b, const int g, const int la
         else if (rem[1]) rem[1] &= rem[1] - 1;
         else rem[2] &= rem[2] - 1;
       }
+#if defined(MSB_STUDY_REPEAT)
+      // study build only (scripts/step_cost.sh): the look-ahead step (or a prefix of it, MSB_STUDY_CUT_AT) and its clone
+      // executed once more, so that the difference of two counter runs is the cost of exactly that
+      for (int rep = 0; rep < MSB_STUDY_REPEAT; rep++) {
+#if defined(MSB_STUDY_CUT_AT)
+        if (active) ce.step(a, MSB_STUDY_CUT_AT);
+#else
+        if (active) ce.step(a);
+#endif
+        const int n_act = n_legal - base < U ? n_legal - base : U;
+        __syncthreads();
+        for (int idx = lane; idx < SG * U; idx += 64)
+          if ((idx & (U - 1)) < n_act) priv[idx] = par[idx / U];
+        __syncthreads();
+      }
+#endif
       PROF_MARK(3);   // clone
       if (active) {
         ce.step(a);

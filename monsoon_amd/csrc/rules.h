@@ -27,7 +27,10 @@ static inline void msb_fault_trace(int code) {
 #endif
 
 #if defined(MSB_COUNT_FRAMES) && !defined(__HIPCC__)
-static long long msb_frame_count[32];   // study build of the host library: handler invocations per frame type, [0] = all, [15] = deepest stack, [16..27] = histogram of sp / 4
+#define MSB_COUNT_EVENT(i_) msb_frame_count[i_]++
+static long long msb_frame_count[64];   // study build of the host library: handler invocations per frame type, [0] = all, [15] = deepest stack, [16..27] = histogram of sp / 4, [32..47] = F_MOVE by state, [48..49] = F_RUNAB by state, [50..] = events inside move()
+#else
+#define MSB_COUNT_EVENT(i_)
 #endif
 
 namespace msb {
@@ -1793,6 +1796,7 @@ struct Engine {
       case MV_BASE_HIT:
         dest = p_unpack((path >> (8 * i)) & 0xff);
       base_hit:
+        MSB_COUNT_EVENT(50);
         tp = dest.y < 0 ? remote() : local();
         player_deal_damage(tp, e_str(e));
         if (pl_base(tp) > 0) {
@@ -1803,6 +1807,7 @@ struct Engine {
       case MV_FIGHT:
         dest = p_unpack((path >> (8 * i)) & 0xff);
       fight:
+        MSB_COUNT_EVENT(51);
         target = at(dest);
         if (target == AT_NONE) goto advance;
         cached = e_str(target);   // target_strength_cached
@@ -1829,6 +1834,7 @@ struct Engine {
       case MV_SELF_DEAD:
         flags |= 1;   // is_attacked
       advance:
+        MSB_COUNT_EVENT(52);
         dest = p_unpack((path >> (8 * i)) & 0xff);
         if (current_id != m.ld8g(eg(e), EO_MOVEID)) goto done;
         if (at(dest) == AT_NONE && e_str(e) > 0) {
@@ -2335,12 +2341,23 @@ struct Engine {
   // Stormbound.step, games/stormbound.py:318-373 (without the observation; see observe.inc).
   // The caller guarantees `action` is in legal_actions().  Returns reward | done << 1 as the reference
   // computes them.  A play leaves frames for run(); so does passing the turn on, which has nothing before it.
+#if defined(MSB_STUDY_REPEAT)
+  // study build (scripts/step_cost.sh): a step that stops early -- cut 1 after begin_step, 2 before run(), 3.. after
+  // cut - 2 rounds of run()'s loop; its result is thrown away by the caller
+  MSB_HD MSB_INL int step(int action, int cut = 0) { return step_impl(action, cut); }
+  MSB_HD MSB_A_STEP int step_impl(int action, int cut) {
+#define MSB_STUDY_CUT(n_) if (cut == (n_)) return 0;
+#define MSB_STUDY_LIMIT (cut >= 3 ? cut - 2 : 1 << 30)
+#else
   MSB_HD MSB_INL int step(int action) { return step_impl(action); }
   MSB_HD MSB_A_STEP int step_impl(int action) {
+#define MSB_STUDY_CUT(n_)
+#endif
     MSB_SCOPE(PS_STEP);
     Wk k{0, 0, 0, 0};
     begin_step();
     if (fault()) return 0;
+    MSB_STUDY_CUT(1)
     int lo = local();
     if (action < 148) {
       // PLACE: card = a//16, tile = a%16 over y=4..1,x=0..3.  USE: card = (a-64)//21, idx = (a-64)%21; the
@@ -2377,7 +2394,12 @@ struct Engine {
       flip();
       k.sp = next_turn_out(k.sp);
     }
+    MSB_STUDY_CUT(2)
+#if defined(MSB_STUDY_REPEAT)
+    run(k, MSB_STUDY_LIMIT);
+#else
     run(k);
+#endif
     if (fault()) return action == 155 ? k.result : 0;   // 0 if the play raised; what was computed before the turn was passed on otherwise
     if (action != 155) k.result = (pl_base(remote()) <= 0 ? 1 : 0) | (have_winner() ? 2 : 0);
     if (m.ld8(H_RNGOVER)) set_fault(FAULT_RNG_OVERRUN);
@@ -2448,9 +2470,15 @@ struct Engine {
   // frame first (a "waterfall": take the first waiting lane's function as a wave-uniform value, serve the lanes
   // holding it, repeat), so the switch runs on a scalar and lanes that are in the same function -- whatever path of
   // calls took them there -- execute it together.
+#if defined(MSB_STUDY_REPEAT)
+  MSB_HD MSB_INL void run(Wk& k, int rounds = 1 << 30) {
+#define MSB_STUDY_ROUND && rounds-- > 0
+#else
   MSB_HD MSB_INL void run(Wk& k) {
+#define MSB_STUDY_ROUND
+#endif
     MSB_SCOPE(PS_COMMAND);   // profiling build: the whole loop (the handlers' own scopes are inside it)
-    while (k.sp > 0 && !fault()) {
+    while (k.sp > 0 && !fault() MSB_STUDY_ROUND) {
       uint32_t hdr = m.sk_ld(k.sp - 1);
       const int fn = hdr_fn(hdr);
       if (M::SKW < SK_CAP && k.sp + SK_NEED > M::SKW && fn != F_EVICTED) wk_evict(k, fn);
@@ -2477,6 +2505,8 @@ struct Engine {
       msb_frame_count[0]++;
       if (k.base + k.sp > msb_frame_count[15]) msb_frame_count[15] = k.base + k.sp;
       msb_frame_count[16 + (k.sp < 47 ? k.sp / 4 : 11)]++;
+      if (fn == F_MOVE) msb_frame_count[32 + (hdr_st(hdr) & 15)]++;
+      if (fn == F_RUNAB) msb_frame_count[48 + (hdr_st(hdr) & 1)]++;
 #endif
       wk_dispatch(k, fn, hdr);
 #endif

@@ -35,5 +35,9 @@ names = ["all", "F_MOVE", "F_RUNAB", "F_CTXLEAVE", "F_DESTROY_TAIL", "F_CMD_TAIL
 print("steps (look-ahead + committed):", steps)
 for i, n in enumerate(names):
     print(f"{n:16s} {c[i]:10d}  {c[i] / steps:6.3f} per step")
+mv = ["ENTRY", "POISONED", "BEFORE_MOVING", "STEP", "BASE_HIT", "FIGHT", "STRUCK", "STRUCK_BACK", "TARGET_DEAD", "SELF_DEAD", "AFTER_ATTACK", "DONE", "START"]
+print("F_MOVE by state:", {n: c[32 + i] for i, n in enumerate(mv) if c[32 + i]})
+print("F_RUNAB by state:", {"start": c[48], "returned": c[49]})
+print("inside move(): base hits", c[50], "fights", c[51], "advances tried", c[52])
 print("deepest stack (words):", c[15])
 print("handler invocations by stack depth / 4:", [c[16 + i] for i in range(12)])
