@@ -202,10 +202,14 @@ class FitnessEvaluator:
         extended / large engines are still created when a schedule first needs them."""
         if self._rollout_fn is None and self.config.mode == "rollout":
             eng = self._engine(0)
-            # one two-decision game: loads the code objects and sizes the launch-time buffers (0.7 s the first time)
+            # one decision of as many games as fill the GPU: loads the code objects and makes the runtime size the
+            # launch-time buffers (work-stack overflow blocks, the queue's scratch) for a full grid -- 0.8 s the first time
             from .cards import deck_indices
             d = deck_indices("N12M")
-            eng.rollout(np.zeros((1, 10)), np.zeros(1, dtype=MATCH_DTYPE), np.stack([d, d])[None], 2)
+            n = min(self.config.max_concurrent_games, 8192)
+            m = np.zeros(n, dtype=MATCH_DTYPE)
+            m["seed"] = np.arange(n)
+            eng.rollout(np.zeros((1, 10)), m, np.stack([d, d])[None], 1)
             eng.reset_stats()
 
     def _hip_rollout(self, weights, matches, deck_pairs, max_turns):
@@ -262,12 +266,12 @@ class FitnessEvaluator:
 
     @staticmethod
     def _dist():
-        try:
-            import torch.distributed as dist
-            if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-                return dist
-        except ImportError:
-            pass
+        """torch.distributed if this process is a rank of an initialised job of more than one rank, else None.  A process
+        that never imported torch.distributed cannot be one: it is not imported here (0.7 s the first time)."""
+        import sys
+        dist = sys.modules.get("torch.distributed")
+        if dist is not None and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            return dist
         return None
 
     # -- Seam F ------------------------------------------------------------------------------
