@@ -276,6 +276,12 @@ __device__ MSB_INL void play_game(const DevBuffers& b, const int g, const int la
       }
       break;
     }
+#if defined(MSB_STUDY_LEGAL)
+    {   // study build (scripts/step_cost.sh): the legal mask computed once more
+      msb_u64x4 lm2 = pe.legal_mask_v();
+      asm volatile("" : : "v"(lm2[0]), "v"(lm2[1]), "v"(lm2[2]) : "memory");
+    }
+#endif
     const msb_u64x4 lm = pe.legal_mask_v();
     // the legal set as wave-uniform scalars; `rem` loses the U lowest actions after every pass, so a lane finds its
     // action among the first U set bits (at most U - 1 steps, on the scalar unit for the common part)
@@ -361,6 +367,14 @@ __device__ MSB_INL void play_game(const DevBuffers& b, const int g, const int la
           // the ten values go to LDS for the winner's sake (argmax below) and feed the score from registers; they are
           // dead before the shuffles, so they never sit in registers across them
           double fa[10];
+#if defined(MSB_STUDY_FEATURES)
+          {   // study build: the candidate's features and its score computed once more
+            double fb[10];
+            ce.features(fb);
+            double s2 = CandEngine::action_score_lds(wf, fb);
+            asm volatile("" : : "v"(s2), "v"(fb[0]), "v"(fb[9]) : "memory");
+          }
+#endif
           ce.features(fa);
           for (int i = 0; i < 10; i++) cf[i] = fa[i];
           s = CandEngine::action_score_lds(wf, fa);

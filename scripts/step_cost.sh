@@ -3,7 +3,9 @@
 # builds that execute every look-ahead step (or a prefix of it: -DMSB_STUDY_CUT_AT) one more time, scripts/ab_build.sh
 # <name> "-DMSB_STUDY_REPEAT=1 ..."; differences per launch are printed by scripts/step_cost.py.
 #   bash scripts/step_cost.sh base=monsoon_amd/libmonsoon_hip.so rep=monsoon_amd/libmonsoon_hip_rep.so ...
-# tag=library[@tree]: `tree` = another source tree with its own bench.py (study_r2/: the round-2 recursive core).
+# Study builds: -DMSB_STUDY_REPEAT=1 [-DMSB_STUDY_CUT_AT=n] (look-ahead step), -DMSB_STUDY_FEATURES=1, -DMSB_STUDY_LEGAL=1.
+# tag=library[@tree]: `tree` = another source tree with its own bench.py and the same study block in its kernels.h (round 3
+# compared itself with round 2's recursive core this way: `git archive 18c1ffb bench.py monsoon_amd include | tar -x -C study_r2`).
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/step_cost
 rm -rf $OUT && mkdir -p $OUT
