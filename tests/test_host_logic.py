@@ -256,3 +256,26 @@ def test_recursion_guard_is_not_a_record_limit_and_strict_mode_raises():
                 assert fe.capacity_faults == 1 and fe.depth_faults == 1 and any("still end on a limit" in str(x.message) for x in w)
         finally:
             F.tiered_rollout = orig
+
+
+def test_single_process_evaluation_does_not_import_torch_distributed():
+    """A process that is not a rank of a torch.distributed job never imports it (it cost generation 0 of a C3 run 0.7 s:
+    profiles/r03_run_c3.json); the sharded path is covered by tests/test_distributed_cpu.py."""
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    code = (
+        "import sys, numpy as np\n"
+        f"sys.path[:0] = [{os.path.dirname(here)!r}, {here!r}]\n"
+        "from monsoon_amd.config import EvolutionaryConfig\n"
+        "from monsoon_amd.fitness import FitnessEvaluator\n"
+        "from monsoon_amd.weights import WeightVector\n"
+        "np.random.seed(1)\n"
+        "pop = [WeightVector(10) for _ in range(4)]\n"
+        "cfg = EvolutionaryConfig(mu=4, lambda_=4, schedule='ring', games_per_individual=2, deck='N12M', max_turns=5)\n"
+        "ev = FitnessEvaluator(cfg, rollout_fn=lambda w, m, d, t: np.tile(np.array([0, 0, 1]), (len(w), 1)))\n"
+        "f = ev.evaluate_population(pop, generation=0)\n"
+        "print(len(f), 'torch.distributed' in sys.modules, 'torch' in sys.modules)\n")
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    assert out.stdout.split() == ["4", "False", "False"], out.stdout
