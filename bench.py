@@ -390,7 +390,8 @@ def bench_ga(args, rank, world, local_rank, barrier, all_sum, all_max):
     from monsoon_amd.weights import WeightVector
     n_ind, gpi, deck, what = GA_WORKLOADS[args.workload]
     cfg = EvolutionaryConfig(mu=n_ind, lambda_=n_ind, schedule="ring", games_per_individual=gpi, deck=deck, max_turns=200,
-                             max_concurrent_games=65536, lanes_per_game=args.lanes)
+                             max_concurrent_games=65536, lanes_per_game=args.lanes,
+                             concurrent_tiers=os.environ.get("MONSOON_CONCURRENT_TIERS", "1") != "0")   # development knob (A/B)
     np.random.seed(42)
     pop = [WeightVector(10) for _ in range(n_ind)]
     ev = FitnessEvaluator(cfg, device=local_rank)

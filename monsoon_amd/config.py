@@ -44,6 +44,7 @@ class EvolutionaryConfig:
     deck: str = "N12M"               # key of monsoon_amd.cards.DECKS, both sides; "random109" = per-game decks of configuration C5 (cards.RANDOM_DECK)
     max_concurrent_games: int = 65536
     lanes_per_game: int = 0          # hot-kernel variant: candidate lanes per game (0 = build default)
+    concurrent_tiers: bool = True    # a schedule with games on both records: the two sub-schedules from two host threads (two handles, two streams)
     ga_on_device: bool = False       # offspring + selection order through monsoon_ga_* (same numpy stream; results within a few ulp of the host's)
 
     # nested-JSON sections of the reference's configs/config.json -> flat fields

@@ -110,7 +110,7 @@ def replace_capacity_faulted(counts, results, steps, faults, matches, replay):
     return len(bad)
 
 
-def tiered_rollout(play, n_rows, matches, deck_pairs):
+def tiered_rollout(play, n_rows, matches, deck_pairs, concurrent=False):
     """A schedule played on the smallest record each game needs.  play(tier, sub_matches, sub_deck_pairs) ->
     (counts[n_rows][3], results, steps, faults) runs matches on one build (tier 0 standard, 1 extended, 2 large record);
     it is handed only the deck pairs its matches name (a build refuses a table holding a card it does not support).
@@ -120,7 +120,9 @@ def tiered_rollout(play, n_rows, matches, deck_pairs):
     109-card decks -- 37 % of whose games hold one of the two -- is split in two sub-schedules.  Then the ladder: games
     that hit a limit of their record (fault code >= 16) are played again on the next larger one and their rows replaced
     (nested b005 memories are deep copies of the whole game, cards/b005.py:14-33, card.py:71-75: the reference's copies
-    nest without bound, a record does not).  Returns (counts, results, steps, faults, replays, tier_sizes)."""
+    nest without bound, a record does not).  concurrent: the standard and the extended sub-schedule are played from two
+    host threads (two handles, a stream each: the wavefronts of one fill the GPU while the other's batch drains or its
+    host side works).  Returns (counts, results, steps, faults, replays, tier_sizes)."""
     from .cards import needs_extended_each
     matches = np.asarray(matches)
     deck_pairs = np.asarray(deck_pairs, dtype=np.uint8).reshape(-1, 2, 12)
@@ -136,13 +138,16 @@ def tiered_rollout(play, n_rows, matches, deck_pairs):
     results = np.zeros(len(matches), dtype=np.int8)
     steps = np.zeros(len(matches), dtype=np.int32)
     faults = np.zeros(len(matches), dtype=np.uint8)
-    sizes = []
-    for t in (0, 1):
-        idx = np.nonzero(tier == t)[0]
-        sizes.append(len(idx))
-        if not len(idx):
-            continue
-        c, r, s_, f = run(t, matches[idx])
+    first = [np.nonzero(tier == t)[0] for t in (0, 1)]
+    sizes = [len(idx) for idx in first]
+    todo = [(t, idx) for t, idx in enumerate(first) if len(idx)]
+    if concurrent and len(todo) == 2:
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(max_workers=2) as pool:
+            done = list(pool.map(lambda ti: run(ti[0], matches[ti[1]]), todo))
+    else:
+        done = [run(t, matches[idx]) for t, idx in todo]
+    for (t, idx), (c, r, s_, f) in zip(todo, done):
         counts += np.asarray(c, dtype=np.int64)
         results[idx], steps[idx], faults[idx] = r, s_, f
     replays = 0
@@ -213,15 +218,20 @@ class FitnessEvaluator:
             eng.reset_stats()
 
     def _hip_rollout(self, weights, matches, deck_pairs, max_turns):
+        import threading
+        lock = threading.Lock()
+
         def play(tier, sub, sub_pairs):
             eng = self._engine(tier)
             before = eng.stats()["lookahead_steps"]
             counts, results, steps = eng.rollout(weights, sub, sub_pairs, max_turns, want_results=True)
-            self.total_env_steps += eng.stats()["lookahead_steps"] - before
-            self.total_decisions += int(steps.sum())
+            with lock:
+                self.total_env_steps += eng.stats()["lookahead_steps"] - before
+                self.total_decisions += int(steps.sum())
             return counts.astype(np.int64), results, steps, eng.rollout_faults(len(sub))
 
-        counts, results, steps, faults, replays, sizes = tiered_rollout(play, len(weights), matches, deck_pairs)
+        counts, results, steps, faults, replays, sizes = tiered_rollout(play, len(weights), matches, deck_pairs,
+                                                                        concurrent=self.config.concurrent_tiers)
         self.capacity_replays += replays
         left = int(record_limited(faults).sum())
         self.capacity_faults += left

@@ -212,6 +212,10 @@ def test_random109_decks_and_per_game_tiers_on_the_cpu_stand_in():
     _, r_e, s_e, f_e = oracle_rollout_tier(w, m, pairs, 40, 1)
     ok = (f_t < 16) & (f_e < 16)
     assert ok.all() and np.array_equal(r_t, r_e) and np.array_equal(s_t, s_e) and np.array_equal(f_t, f_e)
+    # the two sub-schedules from two host threads (what the GPU path does with its two handles): the same rows
+    from monsoon_amd.fitness import tiered_rollout
+    c_c, r_c, s_c, f_c, _, sizes = tiered_rollout(lambda tier, sub, sp: oracle_rollout_tier(w, sub, sp, 40, tier), len(w), m, pairs, concurrent=True)
+    assert sizes == [int((~ext).sum()), int(ext.sum())] and np.array_equal(r_c, r_t) and np.array_equal(s_c, s_t) and np.array_equal(f_c, f_t)
 
 
 def test_recursion_guard_is_not_a_record_limit_and_strict_mode_raises():
@@ -243,7 +247,7 @@ def test_recursion_guard_is_not_a_record_limit_and_strict_mode_raises():
         fe._engine = lambda tier: None
         import monsoon_amd.fitness as F
         orig = F.tiered_rollout
-        F.tiered_rollout = lambda play_, n, mm, pp: tiered_rollout(play, n, mm, pp)
+        F.tiered_rollout = lambda play_, n, mm, pp, concurrent=False: tiered_rollout(play, n, mm, pp, concurrent=concurrent)
         try:
             if strict:
                 import pytest
