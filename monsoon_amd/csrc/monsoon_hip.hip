@@ -655,19 +655,19 @@ static bool card_unsupported(int c) {
 // k_play instantiations of this build (variants.def): each one is a full compilation of the rules core
 // in a translation unit of its own; anything else is refused by monsoon_create.
 #include "variants.def"
-#define X(U, W) const VariantOps* monsoon_variant_##U##_##W();
+#define X(U, W, G) const VariantOps* monsoon_variant_##U##_##W##_##G();
 MSB_VARIANTS(X)
 #undef X
-static const VariantOps* find_variant(int u, int w) {   // w = 0: the build of u lanes with the most waves per SIMD
+static const VariantOps* find_variant(int u, int w, int g) {   // w = 0: the build of u lanes and g games with the most waves per SIMD
   const VariantOps* best = nullptr;
-#define X(U, W) if (u == U && (w == W || (w == 0 && (!best || W > best->wpe)))) best = monsoon_variant_##U##_##W();
+#define X(U, W, G) if (u == U && g == G && (w == W || (w == 0 && (!best || W > best->wpe)))) best = monsoon_variant_##U##_##W##_##G();
   MSB_VARIANTS(X)
 #undef X
   return best;
 }
 static const VariantOps* default_variant() {
   const VariantOps* first = nullptr;
-#define X(U, W) if (!first) first = monsoon_variant_##U##_##W();
+#define X(U, W, G) if (!first) first = monsoon_variant_##U##_##W##_##G();
   MSB_VARIANTS(X)
 #undef X
   return first;
@@ -781,14 +781,16 @@ int monsoon_create(const monsoon_config* cfg, monsoon_t** out) {
   }
   // kernel variant: 0 = this build's default; an explicit value without an instantiation is an error, never a
   // silent substitute (tuning knobs for experiments: MONSOON_LANES / MONSOON_WPE)
-  int u = cfg->lanes_per_game, w = 0;
+  int u = cfg->lanes_per_game, w = 0, gpw = 0;
   if (const char* e = getenv("MONSOON_LANES")) u = atoi(e);
   if (const char* e = getenv("MONSOON_WPE")) w = atoi(e);
+  if (const char* e = getenv("MONSOON_GAMES_PER_WAVE")) gpw = atoi(e);
   const VariantOps* var = default_variant();
-  if (u != 0 || w != 0) {
+  if (u != 0 || w != 0 || gpw != 0) {
     if (u == 0) u = var->lanes;
-    if (w == 0 && u == var->lanes) w = var->wpe;
-    var = find_variant(u, w);
+    if (gpw == 0) gpw = u == var->lanes ? var->games : 1;
+    if (w == 0 && u == var->lanes && gpw == var->games) w = var->wpe;
+    var = find_variant(u, w, gpw);
   }
   if (!var) {
     g_create_error = "monsoon_create: no kernel variant for lanes_per_game=" + std::to_string(u) + " waves_per_simd=" + std::to_string(w) +
@@ -1396,13 +1398,13 @@ static int launch_play(monsoon_t* h, int n, int max_turns, int rounds, int write
   int grid = rounds > 1 ? h->grid_waves : 2 * h->grid_waves;
   if (const char* e = getenv("MONSOON_GRID")) grid = atoi(e);
   // the persistent form needs a wavefront for every one of its POP_PARTS ranges
-  const int pers = (g_persistent && grid < n && grid >= POP_PARTS) ? 1 : 0;
-  if (!pers) grid = n;
-  if ((size_t)grid * v->lanes > h->ovf_lanes) {   // work-stack overflow blocks for every workgroup of this grid
+  const int pers = (g_persistent && (long long)grid * v->games < n && grid >= POP_PARTS) ? 1 : 0;
+  if (!pers) grid = (n + v->games - 1) / v->games;   // a wavefront per v->games games
+  if ((size_t)grid * v->lanes * v->games > h->ovf_lanes) {   // work-stack overflow blocks for every workgroup of this grid
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     HIP_TRY(h, hipFree(h->b.wk_ovf));
     h->b.wk_ovf = nullptr;
-    h->ovf_lanes = (size_t)grid * v->lanes;
+    h->ovf_lanes = (size_t)grid * v->lanes * v->games;
     HIP_TRY(h, hipMalloc(&h->b.wk_ovf, h->ovf_lanes * OVF_WORDS * 4));
   }
   v->play(grid, lds, h->stream, h->b, n, max_turns, rounds, write_scores, pers, h->parity);

@@ -423,6 +423,43 @@ struct SharedMem {   // one contiguous record read by every lane of the wave (LD
   MSB_HD MSB_INL static uint32_t ovf_ld(int) { return 0; }
   MSB_HD MSB_INL static void ovf_st(int, uint32_t) {}
 };
+// The same for a wavefront that plays several games at once (kernels_multi.h): lanes [k*U, (k+1)*U) belong to game slot k,
+// whose current record sits at BASE + k*STRIDE.
+template <int BASE, int STRIDE, int U>
+struct GroupMem {
+  MSB_HD MSB_INL static MSB_AS_LDS uint8_t* b(int o) {
+    return (MSB_AS_LDS uint8_t*)(uintptr_t)(BASE + ((int)__builtin_amdgcn_workitem_id_x() / U) * STRIDE + o);
+  }
+  MSB_HD MSB_INL static int ld8(int o) { return *b(o); }
+  MSB_HD MSB_INL static void st8(int o, int v) { *b(o) = (uint8_t)v; }
+  MSB_HD MSB_INL static int ld16(int o) { return *(MSB_AS_LDS const int16_t*)b(o); }
+  MSB_HD MSB_INL static void st16(int o, int v) { *(MSB_AS_LDS int16_t*)b(o) = (int16_t)v; }
+  MSB_HD MSB_INL static uint32_t ld32(int o) { return *(MSB_AS_LDS const uint32_t*)b(o); }
+  MSB_HD MSB_INL static void st32(int o, uint32_t v) { *(MSB_AS_LDS uint32_t*)b(o) = v; }
+  MSB_HD MSB_INL static double ldf(int o) { return *(MSB_AS_LDS const double*)b(o); }
+  MSB_HD MSB_INL static void stf(int o, double v) { *(MSB_AS_LDS double*)b(o) = v; }
+  MSB_HD MSB_INL static uint64_t ld64(int o) { return *(MSB_AS_LDS const uint64_t*)b(o); }
+  MSB_HD MSB_INL static void st64(int o, uint64_t v) { *(MSB_AS_LDS uint64_t*)b(o) = v; }
+  MSB_HD MSB_INL static msb_u32x4 ld128(int o) { return *(MSB_AS_LDS const msb_u32x4*)b(o); }
+  MSB_HD MSB_INL static void st128(int o, msb_u32x4 v) { *(MSB_AS_LDS msb_u32x4*)b(o) = v; }
+  MSB_HD MSB_INL static int ld8g(int g, int k) { return ld8(g * 16 + k); }
+  MSB_HD MSB_INL static void st8g(int g, int k, int v) { st8(g * 16 + k, v); }
+  MSB_HD MSB_INL static int ld16g(int g, int k) { return ld16(g * 16 + k); }
+  MSB_HD MSB_INL static void st16g(int g, int k, int v) { st16(g * 16 + k, v); }
+  MSB_HD MSB_INL static msb_u32x4 ld128g(int g) { return ld128(g * 16); }
+  MSB_HD MSB_INL static void st128g(int g, msb_u32x4 v) { st128(g * 16, v); }
+  MSB_HD MSB_INL static uint32_t ld32g(int g, int k) { return ld32(g * 16 + k); }
+  MSB_HD MSB_INL static void st32g(int g, int k, uint32_t v) { st32(g * 16 + k, v); }
+  MSB_HD MSB_INL static double ldfg(int g, int k) { return ldf(g * 16 + k); }
+  MSB_HD MSB_INL static void stfg(int g, int k, double v) { stf(g * 16 + k, v); }
+  MSB_HD MSB_INL static double wtab(int age) { return lds_wtab(age); }
+  MSB_HD MSB_INL static void trace_ability(int, int) {}
+  static constexpr int SKW = SK_CAP;   // (read only, like SharedMem: nothing is stepped through it)
+  MSB_HD MSB_INL static uint32_t sk_ld(int) { return 0; }
+  MSB_HD MSB_INL static void sk_st(int, uint32_t) {}
+  MSB_HD MSB_INL static uint32_t ovf_ld(int) { return 0; }
+  MSB_HD MSB_INL static void ovf_st(int, uint32_t) {}
+};
 #endif
 
 template <class A, class B>

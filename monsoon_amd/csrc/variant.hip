@@ -1,20 +1,32 @@
-// One instantiation of the hot kernel (kernels.h): compile with -DVAR_U=<candidate lanes per game>
-// -DVAR_W=<waves per SIMD>.  Exports monsoon_variant_<U>_<W>(), the launch table monsoon_hip.hip uses.
-#include "kernels.h"
+// One instantiation of the hot kernel: compile with -DVAR_U=<candidate lanes per game> -DVAR_W=<waves per SIMD>
+// [-DVAR_G=<games per wavefront>].  G = 1 is k_play (kernels.h), more is k_play_multi (kernels_multi.h).  Exports
+// monsoon_variant_<U>_<W>_<G>(), the launch table monsoon_hip.hip uses.
+#include "kernels_multi.h"
 
 using namespace msbk;
 
+#ifndef VAR_G
+#define VAR_G 1
+#endif
+
 namespace {
+#if VAR_G == 1
+#define VAR_KERNEL k_play<VAR_U, VAR_W>
+constexpr int kLds = DecideLds<VAR_U>::TOTAL;
+#else
+#define VAR_KERNEL k_play_multi<VAR_U, VAR_G, VAR_W>
+constexpr int kLds = MultiLds<VAR_U, VAR_G>::TOTAL;
+#endif
 hipError_t v_occupancy(int* blocks_per_cu, int lds_bytes) {
-  return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, k_play<VAR_U, VAR_W>, 64, lds_bytes);
+  return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, VAR_KERNEL, 64, lds_bytes);
 }
 void v_play(int grid, int lds_bytes, hipStream_t stream, DevBuffers b, int n, int max_turns, int rounds, int write_scores, int persistent,
             int parity) {
-  hipLaunchKernelGGL((k_play<VAR_U, VAR_W>), dim3(grid), dim3(64), lds_bytes, stream, b, n, max_turns, rounds, write_scores, persistent, parity);
+  hipLaunchKernelGGL((VAR_KERNEL), dim3(grid), dim3(64), lds_bytes, stream, b, n, max_turns, rounds, write_scores, persistent, parity);
 }
-const VariantOps kOps = {VAR_U, VAR_W, DecideLds<VAR_U>::TOTAL, v_occupancy, v_play};
+const VariantOps kOps = {VAR_U, VAR_W, VAR_G, kLds, v_occupancy, v_play};
 }  // namespace
 
-#define MSB_CAT_(a, b, c) a##b##_##c
-#define MSB_CAT(a, b, c) MSB_CAT_(a, b, c)
-const VariantOps* MSB_CAT(monsoon_variant_, VAR_U, VAR_W)() { return &kOps; }
+#define MSB_CAT_(a, b, c, d) a##b##_##c##_##d
+#define MSB_CAT(a, b, c, d) MSB_CAT_(a, b, c, d)
+const VariantOps* MSB_CAT(monsoon_variant_, VAR_U, VAR_W, VAR_G)() { return &kOps; }

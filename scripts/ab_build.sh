@@ -6,7 +6,7 @@ set -e
 cd "$(dirname "$0")/../monsoon_amd/csrc"
 make -s -j8 ../libmonsoon_hip.so
 BASE="-O3 -std=c++17 -ffp-contract=off -fno-strict-aliasing -mllvm -disable-promote-alloca-to-lds=true -mllvm -enable-ipra=0 -fPIC -Wno-unused-value"
-OTHERS=$(ls build/std/*.o | grep -v variant_8_5.o)
+OTHERS=$(ls build/std/*.o | grep -v variant_8_5_1.o)
 while [ $# -ge 2 ]; do
   name=$1; extra=$2; shift 2
   flags=$BASE; add=""

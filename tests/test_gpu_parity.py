@@ -196,6 +196,52 @@ def test_rollout_vs_oracle_2048_games(engines, lanes):
     assert st["capacity_faults"] == 0 and st["lookahead_capacity_faults"] == 0
 
 
+@pytest.mark.parametrize("games_per_wave", [2, 4])
+def test_several_games_per_wavefront_give_the_same_games(monkeypatch, games_per_wave):
+    """k_play_multi (csrc/kernels_multi.h: a wavefront plays 2 or 4 games at once, lanes [8k, 8k+8) game slot k; a
+    development variant, slower than the default -- profiles/r03_ab_games_per_wave.txt): whole rollouts, a ragged tail, a
+    schedule of two weight vectors and the 8-decisions-per-launch form all equal the CPU replay."""
+    from monsoon_amd.engine import BatchEngine
+    monkeypatch.setenv("MONSOON_GAMES_PER_WAVE", str(games_per_wave))
+    n = 3001   # not a multiple of the slots: the last wavefront of the non-persistent form has empty slots
+    deck = deck_indices("N12M")
+    eng = BatchEngine(8192)
+    try:
+        w2 = np.stack([W0, np.random.RandomState(5).uniform(0, 1, 10)])
+        matches = np.zeros(n, dtype=[("p1", "<i4"), ("p2", "<i4"), ("seed", "<u4"), ("deck", "<u4")])
+        matches["seed"] = np.arange(n) + 300000
+        matches["p2"] = np.arange(n) % 2
+        counts, results, steps = eng.rollout(w2, matches, np.stack([deck, deck])[None], 200, want_results=True)
+        hashes = eng.state_hash()
+        orc = oracle_lib.Oracle(n)
+        ores, osteps, ohash = np.zeros(n, np.int8), np.zeros(n, np.int32), np.zeros(n, np.uint64)
+        for i in range(n):
+            orc.reset(i, 300000 + i, deck, deck)
+            r = orc.rollout(i, w2[0], w2[i % 2], 200)
+            ores[i], osteps[i], ohash[i] = r["result"], r["steps"], orc.canon_hash(i)
+        assert np.array_equal(results, ores) and np.array_equal(steps, osteps) and np.array_equal(hashes[:n], ohash)
+        assert counts[0, 2] == n
+        # decision rounds of 8 192 games (the persistent form: more games than slots), 8 per launch, against the default kernel
+        monkeypatch.delenv("MONSOON_GAMES_PER_WAVE")
+        ref = BatchEngine(8192)
+        try:
+            assert ref.variant()[0] == 8
+            for e in (eng, ref):
+                e.reset(np.arange(8192, dtype=np.uint32) + 7, np.stack([deck, deck]))
+                e.reset_stats()
+                e.upload_weights(w2)
+                e.assign_players(np.zeros(8192, dtype=np.int32), (np.arange(8192) % 2).astype(np.int32))
+                for _ in range(3):
+                    e.play_rounds(8)
+                e.sync()
+            assert np.array_equal(eng.state_hash(), ref.state_hash())
+            assert eng.stats()["lookahead_steps"] == ref.stats()["lookahead_steps"]
+        finally:
+            ref.close()
+    finally:
+        eng.close()
+
+
 def test_unknown_kernel_variant_is_refused():
     from monsoon_amd._lib import MonsoonError
     from monsoon_amd.engine import BatchEngine
