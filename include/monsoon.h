@@ -38,8 +38,9 @@ typedef struct {
   int32_t max_games;       /* capacity of the batch */
   int32_t lanes_per_game;  /* candidate lanes (successor states stepped at once) per game: 4, 8, 16, 32 or 64; 0 = default.
                               Must be a kernel variant of the build (monsoon_amd/csrc/variants.def), else create fails.
-                              (Development knobs read at create: MONSOON_LANES, MONSOON_WPE, MONSOON_GAMES_PER_WAVE = 2 | 4:
-                              the several-games-per-wavefront form of the hot kernel, same results, slower.) */
+                              (Development knobs read at create: MONSOON_LANES, MONSOON_WPE, and MONSOON_GAMES_PER_WAVE = the
+                              kind of hot kernel: 10 the game's record in registers (default of the standard build), 1 in LDS,
+                              2 | 4 several games per wavefront -- same results, slower.) */
   int32_t stack_bytes;     /* ignored since the rules core keeps an explicit work stack (kept for ABI compatibility) */
 } monsoon_config;
 

@@ -514,7 +514,8 @@ __global__ void __launch_bounds__(64, WPE) k_play(DevBuffers b, int n, int max_t
 // What the host needs to launch one variant (variant.hip defines one getter per instantiation).
 struct VariantOps {
   int lanes, wpe;           // U, W
-  int games;                // G: games a wavefront plays at once (1: k_play; more: k_play_multi, kernels_multi.h)
+  int kind;                 // variants.def's third column: 1 k_play, 2 / 4 k_play_multi, 10 k_play_reg
+  int games;                // games a wavefront plays at once (k_play_multi: 2 or 4; else 1)
   int lds_bytes;            // dynamic LDS of one workgroup
   hipError_t (*occupancy)(int* blocks_per_cu, int lds_bytes);
   void (*play)(int grid, int lds_bytes, hipStream_t stream, DevBuffers b, int n, int max_turns, int rounds, int write_scores, int persistent,

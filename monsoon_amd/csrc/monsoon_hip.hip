@@ -658,7 +658,7 @@ static bool card_unsupported(int c) {
 #define X(U, W, G) const VariantOps* monsoon_variant_##U##_##W##_##G();
 MSB_VARIANTS(X)
 #undef X
-static const VariantOps* find_variant(int u, int w, int g) {   // w = 0: the build of u lanes and g games with the most waves per SIMD
+static const VariantOps* find_variant(int u, int w, int g) {   // g: the kind of kernel (variants.def); w = 0: the one with the most waves per SIMD
   const VariantOps* best = nullptr;
 #define X(U, W, G) if (u == U && g == G && (w == W || (w == 0 && (!best || W > best->wpe)))) best = monsoon_variant_##U##_##W##_##G();
   MSB_VARIANTS(X)
@@ -788,8 +788,8 @@ int monsoon_create(const monsoon_config* cfg, monsoon_t** out) {
   const VariantOps* var = default_variant();
   if (u != 0 || w != 0 || gpw != 0) {
     if (u == 0) u = var->lanes;
-    if (gpw == 0) gpw = u == var->lanes ? var->games : 1;
-    if (w == 0 && u == var->lanes && gpw == var->games) w = var->wpe;
+    if (gpw == 0) gpw = u == var->lanes ? var->kind : 1;   // the default's kind of kernel where it has the lanes asked for
+    if (w == 0 && u == var->lanes && gpw == var->kind) w = var->wpe;
     var = find_variant(u, w, gpw);
   }
   if (!var) {

@@ -46,7 +46,7 @@ constexpr int DECK_SIZE = 12;  // cards per deck at construction (games/stormbou
 #if MSB_EXT == 2
 constexpr int DECK_CAP = 48;   // ua20 keeps appending single-use copies (cards/ua20.py:27-32): 2 of 131 072 C5 games pass 32 entries
 #else
-constexpr int DECK_CAP = 32;
+constexpr int DECK_CAP = 28;   // (32 until round 3: 64 bytes less per record let a seventh wavefront into a CU's LDS)
 #endif
 #if defined(MSB_CAP_REM)       // capacity studies (scripts/c5_capacity.py)
 constexpr int REM_LISTS = MSB_CAP_REM, WORLD_CAP = MSB_CAP_WORLD;
@@ -418,6 +418,42 @@ struct SharedMem {   // one contiguous record read by every lane of the wave (LD
   MSB_HD MSB_INL static void trace_ability(int, int) {}
   // the shared copy is only read (legal mask, features): nothing is ever stepped through it
   static constexpr int SKW = SK_CAP;
+  MSB_HD MSB_INL static uint32_t sk_ld(int) { return 0; }
+  MSB_HD MSB_INL static void sk_st(int, uint32_t) {}
+  MSB_HD MSB_INL static uint32_t ovf_ld(int) { return 0; }
+  MSB_HD MSB_INL static void ovf_st(int, uint32_t) {}
+};
+// Column 0 of a lane-interleaved image (LaneMem<LANES, BASE, ..>), addressed by every lane alike: where kernels_reg.h keeps
+// the LDS image of the game's current record (the record itself lives in registers there).  Read-mostly like SharedMem.
+template <int LANES, int BASE>
+struct Col0Mem {
+  MSB_HD MSB_INL static MSB_AS_LDS uint8_t* b(int o) { return (MSB_AS_LDS uint8_t*)(uintptr_t)(BASE + (o >> 4) * (LANES * 16) + (o & 15)); }
+  MSB_HD MSB_INL static MSB_AS_LDS uint8_t* gb(int g, int k) { return (MSB_AS_LDS uint8_t*)(uintptr_t)(BASE + g * (LANES * 16) + k); }
+  MSB_HD MSB_INL static int ld8(int o) { return *b(o); }
+  MSB_HD MSB_INL static void st8(int o, int v) { *b(o) = (uint8_t)v; }
+  MSB_HD MSB_INL static int ld16(int o) { return *(MSB_AS_LDS const int16_t*)b(o); }
+  MSB_HD MSB_INL static void st16(int o, int v) { *(MSB_AS_LDS int16_t*)b(o) = (int16_t)v; }
+  MSB_HD MSB_INL static uint32_t ld32(int o) { return *(MSB_AS_LDS const uint32_t*)b(o); }
+  MSB_HD MSB_INL static void st32(int o, uint32_t v) { *(MSB_AS_LDS uint32_t*)b(o) = v; }
+  MSB_HD MSB_INL static double ldf(int o) { return *(MSB_AS_LDS const double*)b(o); }
+  MSB_HD MSB_INL static void stf(int o, double v) { *(MSB_AS_LDS double*)b(o) = v; }
+  MSB_HD MSB_INL static uint64_t ld64(int o) { return *(MSB_AS_LDS const uint64_t*)b(o); }
+  MSB_HD MSB_INL static void st64(int o, uint64_t v) { *(MSB_AS_LDS uint64_t*)b(o) = v; }
+  MSB_HD MSB_INL static msb_u32x4 ld128(int o) { return *(MSB_AS_LDS const msb_u32x4*)b(o); }
+  MSB_HD MSB_INL static void st128(int o, msb_u32x4 v) { *(MSB_AS_LDS msb_u32x4*)b(o) = v; }
+  MSB_HD MSB_INL static int ld8g(int g, int k) { return *gb(g, k); }
+  MSB_HD MSB_INL static void st8g(int g, int k, int v) { *gb(g, k) = (uint8_t)v; }
+  MSB_HD MSB_INL static int ld16g(int g, int k) { return *(MSB_AS_LDS const int16_t*)gb(g, k); }
+  MSB_HD MSB_INL static void st16g(int g, int k, int v) { *(MSB_AS_LDS int16_t*)gb(g, k) = (int16_t)v; }
+  MSB_HD MSB_INL static msb_u32x4 ld128g(int g) { return *(MSB_AS_LDS const msb_u32x4*)gb(g, 0); }
+  MSB_HD MSB_INL static void st128g(int g, msb_u32x4 v) { *(MSB_AS_LDS msb_u32x4*)gb(g, 0) = v; }
+  MSB_HD MSB_INL static uint32_t ld32g(int g, int k) { return *(MSB_AS_LDS const uint32_t*)gb(g, k); }
+  MSB_HD MSB_INL static void st32g(int g, int k, uint32_t v) { *(MSB_AS_LDS uint32_t*)gb(g, k) = v; }
+  MSB_HD MSB_INL static double ldfg(int g, int k) { return *(MSB_AS_LDS const double*)gb(g, k); }
+  MSB_HD MSB_INL static void stfg(int g, int k, double v) { *(MSB_AS_LDS double*)gb(g, k) = v; }
+  MSB_HD MSB_INL static double wtab(int age) { return lds_wtab(age); }
+  MSB_HD MSB_INL static void trace_ability(int, int) {}
+  static constexpr int SKW = SK_CAP;   // (nothing is stepped through it)
   MSB_HD MSB_INL static uint32_t sk_ld(int) { return 0; }
   MSB_HD MSB_INL static void sk_st(int, uint32_t) {}
   MSB_HD MSB_INL static uint32_t ovf_ld(int) { return 0; }

@@ -196,11 +196,13 @@ def test_rollout_vs_oracle_2048_games(engines, lanes):
     assert st["capacity_faults"] == 0 and st["lookahead_capacity_faults"] == 0
 
 
-@pytest.mark.parametrize("games_per_wave", [2, 4])
-def test_several_games_per_wavefront_give_the_same_games(monkeypatch, games_per_wave):
-    """k_play_multi (csrc/kernels_multi.h: a wavefront plays 2 or 4 games at once, lanes [8k, 8k+8) game slot k; a
-    development variant, slower than the default -- profiles/r03_ab_games_per_wave.txt): whole rollouts, a ragged tail, a
-    schedule of two weight vectors and the 8-decisions-per-launch form all equal the CPU replay."""
+@pytest.mark.parametrize("games_per_wave", [1, 2, 4])
+def test_the_other_kinds_of_hot_kernel_give_the_same_games(monkeypatch, games_per_wave):
+    """The standard build's default hot kernel keeps a game's record in registers (csrc/kernels_reg.h).  The other kinds at
+    8 lanes -- k_play with the record in LDS (kind 1, the kernel of the other builds and lane counts) and k_play_multi
+    (csrc/kernels_multi.h: a wavefront plays 2 or 4 games at once, lanes [8k, 8k+8) game slot k; slower,
+    profiles/r03_ab_games_per_wave.txt) -- play the same games: whole rollouts, a ragged tail, a schedule of two weight
+    vectors and the 8-decisions-per-launch form all equal the CPU replay and the default kernel."""
     from monsoon_amd.engine import BatchEngine
     monkeypatch.setenv("MONSOON_GAMES_PER_WAVE", str(games_per_wave))
     n = 3001   # not a multiple of the slots: the last wavefront of the non-persistent form has empty slots
