@@ -1,5 +1,6 @@
 // kernels.h -- device code shared by every translation unit of libmonsoon_hip.so: per-game buffers, stream-block
-// maintenance, and the hot kernel k_play as a template over {candidate lanes per game U, waves per SIMD W}.  Each
+// maintenance, and the hot kernel k_play as a template over {candidate lanes per game U, waves per SIMD W} (the builds'
+// default is its sibling k_play_reg, kernels_reg.h: the same decision loop with the game's record in registers).  Each
 // instantiation is a full compilation of the rules core, so every variant lives in a translation unit of its own
 // (variant.hip, built in parallel by the Makefile); monsoon_hip.hip holds the API kernels and the host side.
 //

@@ -24,8 +24,8 @@ constexpr int NUM_ENT = MSB_CAP_ENT;   // capacity studies (scripts/c5_capacity.
 #elif defined(MSB_EXT) && MSB_EXT == 2
 constexpr int NUM_ENT = 254;  // the LARGE record: every slot id a byte can name (0xFE / 0xFF are markers)
 #elif defined(MSB_EXT) && MSB_EXT
-// 20 tiles + transient + b005's remembered copies + the entities of frozen world snapshots.  Round 3: 64 slots (2 832-byte record)
-// instead of 128 (4 240): 8 instead of 4 candidate lanes fit a wavefront's LDS and the extended tier of a C5 generation runs 1.4x
+// 20 tiles + transient + b005's remembered copies + the entities of frozen world snapshots.  Round 3: 64 slots (2 832-byte record,
+// 2 752 with 28 deck entries) instead of 128 (4 240): 8 instead of 4 candidate lanes fit a wavefront's LDS and the extended tier of a C5 generation runs 1.4x
 // faster; 0.9 % instead of 0.2 % of random-deck games then need the large record (scripts/c5_capacity.py --ent 64), which the
 // ladder gives them.
 constexpr int NUM_ENT = 64;
