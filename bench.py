@@ -433,7 +433,9 @@ def bench_ga(args, rank, world, local_rank, barrier, all_sum, all_max):
                          "left_on_a_record_limit": ev.capacity_faults},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                      "kernel": "k_play (rank 0, all record tiers)", "kernel_ms_per_step": kms / max(args.steps, 1), "launches": launches,
-                     "host_and_other_ms_per_step": 1000.0 * dt / args.steps - kms / max(args.steps, 1)},
+                     # kernel time is summed over the handles of the record tiers, whose launches overlap when a schedule
+                     # has games on two records (config.concurrent_tiers): the difference is only meaningful for one tier
+                     "host_and_other_ms_per_step": (1000.0 * dt / args.steps - kms / max(args.steps, 1)) if ev.tier_games[1] == 0 or not cfg.concurrent_tiers else None},
     }
 
 
