@@ -53,8 +53,10 @@ constexpr int REM_LISTS = MSB_CAP_REM, WORLD_CAP = MSB_CAP_WORLD;
 #elif MSB_EXT == 2             // the LARGE record: where monsoon_rollout replays the games the extended record cannot hold
 constexpr int REM_LISTS = 64, WORLD_CAP = 16;
 #else
-constexpr int REM_LISTS = 16;  // memory lists (one per b005 with a pending memory, nested ones included)
-constexpr int WORLD_CAP = 8;   // frozen world snapshots alive at once (see below)
+// 8 lists and 4 worlds (16 and 8 until late round 3): 2 400 instead of 2 752 bytes, an eighth wavefront in a CU's LDS; 1.03 %
+// instead of 0.92 % of random-deck games then move on to the large record (scripts/c5_capacity.py --ent 64 --rem 8 --world 4)
+constexpr int REM_LISTS = 8;   // memory lists (one per b005 with a pending memory, nested ones included)
+constexpr int WORLD_CAP = 4;   // frozen world snapshots alive at once (see below)
 #endif
 static_assert(REM_LISTS <= 64 && WORLD_CAP < 32, "rem_collect keeps the live lists in a 64-bit and the live worlds in a 32-bit set");
 #else
