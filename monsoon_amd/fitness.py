@@ -115,7 +115,7 @@ def tiered_rollout(play, n_rows, matches, deck_pairs, concurrent=False):
     (counts[n_rows][3], results, steps, faults) runs matches on one build (tier 0 standard, 1 extended, 2 large record);
     it is handed only the deck pairs its matches name (a build refuses a table holding a card it does not support).
 
-    Tier per GAME, not per call: only a deck pair holding ua20 / b005 needs the extended record (2 752 bytes against
+    Tier per GAME, not per call: only a deck pair holding ua20 / b005 needs the extended record (2 400 bytes against
     752: the hot kernel runs half as many wavefronts with half as many candidate lanes on it), so a schedule of random
     109-card decks -- 37 % of whose games hold one of the two -- is split in two sub-schedules.  Then the ladder: games
     that hit a limit of their record (fault code >= 16) are played again on the next larger one and their rows replaced
